@@ -1,0 +1,38 @@
+"""pytest configuration: the ``gpu`` marker and shared fixtures.
+
+``-m "not gpu"`` tests run in the build container (no GPU): the oracle against the golden vectors,
+host logic, C-ABI symbol export, the host-emulated kernel math.  ``-m gpu`` tests are the parity
+tests proper and call the HIP kernels through the C-ABI on an MI355X.
+"""
+
+import os
+import os.path as osp
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = osp.dirname(osp.dirname(osp.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def model_root():
+    from smplfitter_amd import synth
+
+    return synth.ensure_model_root(kinds=('smpl', 'smplx'), seed=0)
+
+
+@pytest.fixture(scope='session')
+def golden():
+    gdir = osp.join(ROOT, 'tests', 'golden')
+
+    def load(name):
+        return dict(np.load(osp.join(gdir, f'golden_{name}.npz'), allow_pickle=False))
+
+    return load

@@ -1,0 +1,97 @@
+"""Pin the CPU oracle against the golden vectors captured from the reference
+(tests/golden/make_golden.py).  Tolerances follow BASELINE.md §5: vertices are the gate (1e-4 m);
+betas/trans 1e-4-class; pose_rotvecs sits at the reference's own fp32 noise floor."""
+
+import numpy as np
+import pytest
+
+import util
+from oracle import smplfit_oracle as O
+from smplfitter_amd import synth
+
+
+@pytest.mark.parametrize('name', ['smpl', 'smplx', 'smpl1024'])
+def test_model_digest_and_forward(name, model_root, golden):
+    g = golden(name)
+    kind, md = util.load_md(model_root, name, g)
+    assert synth.model_sha256(synth.make_model_arrays(kind, 0)) == str(g['model_sha256'])
+    om, _ = util.make_oracle(md, kind)
+    fw = om.forward(g['pose'], g['betas'], g['trans'])
+    assert np.abs(fw['vertices'][:, ::300] - g['fwd_vertices_sub']).max() < 2e-6
+    assert np.abs(fw['joints'] - g['fwd_joints']).max() < 2e-6
+    assert np.abs(fw['vertices'] - g['target_vertices']).max() < 2e-6
+    assert np.abs(fw['orientations'] - g['fwd_orientations']).max() < 1e-6
+
+
+@pytest.mark.parametrize('name', ['smpl', 'smplx', 'smpl1024'])
+def test_stage_goldens(name, model_root, golden):
+    g = golden(name)
+    kind, md = util.load_md(model_root, name, g)
+    om, of = util.make_oracle(md, kind)
+    tv, tj = g['target_vertices'], g['target_joints']
+    mean = np.concatenate([tv, tj], 1).mean(1)
+    tvc, tjc = tv - mean[:, None], tj - mean[:, None]
+    raw, st, sa, sw = of.part_sums(tvc, of.default_mesh[None], None)
+    scale = np.abs(g['stage.part_sums.raw']).max()
+    assert np.abs(raw - g['stage.part_sums.raw']).max() < 2e-5 * max(scale, 1.0)
+    # fp32 sums of ~300 terms in a different order: 3e-5 relative to the largest sum
+    assert np.abs(st - g['stage.part_sums.s_t']).max() < 3e-5 * np.abs(g['stage.part_sums.s_t']).max()
+    assert np.abs(sa - g['stage.part_sums.s_a']).max() < 3e-5 * np.abs(g['stage.part_sums.s_a']).max()
+    assert np.abs(sw - g['stage.part_sums.s_w']).max() == 0
+    G0 = of.fit_global_rotations(tvc, tjc, of.default_mesh[None], om.J_template[None], None, None)
+    assert np.abs(G0 - g['stage.glob_rotmats_iter0']).max() < (2e-3 if name == 'smplx' else 5e-4)
+    # shape solve on the reference's own rotations isolates the solve from rotation noise
+    r = of.fit_shape(g['stage.glob_rotmats_iter0'], tvc, tjc, None, None, 1.0, 0.0)
+    # fp32 Gramian + centring cancellation: 1e-4-class on the thin-part SMPL-X fixture
+    assert np.abs(r['shape_betas'] - g['stage.shape_betas0']).max() < (3e-4 if name == 'smplx' else 5e-5)
+    assert np.abs(r['trans'] - g['stage.trans0']).max() < 1e-5
+    assert np.abs(r['joints'] - g['stage.joints0']).max() < 2e-5
+    assert np.abs(r['vertices'][:, ::300] - g['stage.vertices0_sub']).max() < 2e-5
+
+
+@pytest.mark.parametrize('name', ['smpl', 'smplx', 'smpl1024'])
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_fit_goldens(name, dtype, model_root, golden):
+    g = golden(name)
+    kind, md = util.load_md(model_root, name, g)
+    om, of = util.make_oracle(md, kind, dtype)
+    om64, _ = util.make_oracle(md, kind, np.float64)
+    pose_tol = 5e-3 if name == 'smplx' else 1.5e-3
+    for c in util.fit_configs(g):
+        cfg = util.cfg_from_name(c)
+        o = of.fit(
+            g['target_vertices'],
+            g['target_joints'] if cfg['joints'] else None,
+            vertex_weights=g['vertex_weights'] if cfg['weights'] else None,
+            joint_weights=g['joint_weights'] if (cfg['weights'] and cfg['joints']) else None,
+            num_iter=cfg['num_iter'], beta_regularizer=cfg['beta_regularizer'],
+            final_adjust_rots=cfg['final_adjust_rots'],
+        )
+        ref = {k: g[f'fit.{c}.{k}'] for k in ('pose_rotvecs', 'shape_betas', 'trans', 'orientations')}
+        assert util.vertex_l2(om64, o, ref) < 1e-4, c
+        assert np.abs(o['shape_betas'] - ref['shape_betas']).max() < 3e-4, c
+        assert np.abs(o['trans'] - ref['trans']).max() < 1e-5, c
+        assert np.abs(o['pose_rotvecs'] - ref['pose_rotvecs']).max() < pose_tol, c
+        assert np.abs(o['orientations'] - ref['orientations']).max() < pose_tol, c
+
+
+def test_primitive_goldens(golden):
+    g = golden('primitives')
+    n = int(g['proj_n_random'])
+    A = g['proj_in']
+    out = O.proj_so3(A)
+    assert np.abs(out[:n] - g['proj_out'][:n]).max() < 2e-5
+    # degenerate inputs: the projection must still be a proper rotation
+    det = np.linalg.det(out.astype(np.float64))
+    orth = np.abs(out @ np.swapaxes(out, -1, -2) - np.eye(3)).max()
+    assert np.abs(det - 1).max() < 1e-4 and orth < 1e-4
+    for i in (n + 2, n + 3, n + 5, n + 6, n + 7, n + 8):  # well-defined degenerate cases
+        assert np.abs(out[i] - g['proj_out'][i]).max() < 1e-4, i
+    R = O.rotvec2mat(g['rotvec_in'])
+    assert np.abs(R - g['rotvec2mat_out']).max() < 1e-6
+    rv = O.mat2rotvec(g['rotvec2mat_out'])
+    assert np.abs(rv - g['mat2rotvec_out']).max() < 1e-5
+    Ra = O.align_unit_vectors(g['align_a'], g['align_b'])
+    # last 4 pairs are antiparallel: the reference's answer there is a 180-degree turn about a
+    # rounding-noise axis ("arbitrary", pt/rotation.py:217) — only the defined cases are pinned
+    assert np.abs(Ra[:-4] - g['align_out'][:-4]).max() < 1e-6
