@@ -1,0 +1,160 @@
+/*
+ * smplfit.h — C-ABI of the MI355X-native SMPL-family fitter (libsmplfit_hip.so).
+ *
+ * Drop-in boundary for ONE hot path of isarandi/smplfitter: smplfitter.pt.BodyFitter.fit()
+ * (reference src/smplfitter/pt/bodyfitter.py:283-549) and the LBS forward it is scored with
+ * (reference src/smplfitter/pt/bodymodel.py:121-307).  The reference is pure Python/PyTorch and has
+ * no FFI of its own; these entry points are what a ctypes binding inside its BodyFitter /
+ * BodyModel would call (see INTEGRATION.md for that stub).  Plain pointers and sizes only — no
+ * torch types.  All array arguments of the compute calls are DEVICE pointers (HIP, gfx950), fp32,
+ * C-contiguous; all work is enqueued on the caller's stream; nothing synchronises the device.
+ *
+ * Ownership: the handle owns the uploaded model constants and derived tables only.  The caller
+ * owns inputs, outputs and the workspace (size from smplfit_workspace_bytes).  A handle is
+ * read-only after creation: concurrent calls on different streams are safe if their workspaces
+ * are distinct.
+ *
+ * Errors: every call returns 0 on success or a negative smplfit_status; smplfit_last_error()
+ * returns a thread-local message.  No exceptions cross the boundary.  A non-SPD Gramian yields NaN
+ * outputs (the reference discards cholesky_ex's info, pt/bodyfitter.py:1083).
+ */
+#ifndef SMPLFIT_H_
+#define SMPLFIT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smplfit_handle smplfit_handle;
+
+typedef enum smplfit_status {
+  SMPLFIT_OK = 0,
+  SMPLFIT_ERR_BAD_ARG = -1,     /* null pointer, bad size, option conflict                 */
+  SMPLFIT_ERR_UNSUPPORTED = -2, /* model shape / option outside what the kernels implement */
+  SMPLFIT_ERR_WORKSPACE = -3,   /* workspace too small / misaligned                         */
+  SMPLFIT_ERR_HIP = -4,         /* HIP runtime error (no device, launch failure, OOM)       */
+} smplfit_status;
+
+/* Model constants as the reference's BodyModel holds them (pt/bodymodel.py:80-93), HOST pointers,
+ * fp32, C-contiguous, original vertex order.  Copied during smplfit_create. */
+typedef struct smplfit_model_desc {
+  int32_t num_vertices;            /* V                                                        */
+  int32_t num_joints;              /* J (<= 64)                                                */
+  int32_t num_betas;               /* S                                                        */
+  int32_t is_smpl_family;          /* model_name.startswith('smpl') (pt/bodyfitter.py:34)      */
+  const float* v_template;         /* (V,3)  identity-pose corrective already folded in        */
+  const float* shapedirs;          /* (V,3,S)                                                  */
+  const float* posedirs;           /* (V,3,9(J-1))                                             */
+  const float* weights;            /* (V,J) dense skinning weights                             */
+  const float* J_template;         /* (J,3)                                                    */
+  const float* J_shapedirs;        /* (J,3,S)                                                  */
+  const int32_t* parents;          /* (J) kinematic parents, parents[0] ignored                */
+  const float* J_regressor_post_lbs; /* (J, regressor_num_vertices) or NULL                    */
+  int32_t regressor_num_vertices;  /* must equal V for the joints-omitted path                 */
+} smplfit_model_desc;
+
+enum { SMPLFIT_CREATE_HOST_ONLY = 1 }; /* build tables, upload nothing (no GPU needed)         */
+
+/* Builds the part / level / sparse-skinning tables of BodyFitter.__init__
+ * (pt/bodyfitter.py:25-233) and uploads model + tables to the current HIP device. */
+int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** out);
+void smplfit_destroy(smplfit_handle* h);
+
+const char* smplfit_last_error(void);
+const char* smplfit_version(void);
+
+typedef struct smplfit_info {
+  int32_t num_vertices, num_joints, num_betas;
+  int32_t padded_vertices;     /* Vp: vertices padded for the kernels                          */
+  int32_t num_used_vertices;   /* vertices entering the part sums (pt/bodyfitter.py:109-114)   */
+  int32_t skin_width;          /* non-zero skinning weights kept per vertex (4 or 8)           */
+  int32_t num_segments;        /* part-aligned 64-vertex tiles                                 */
+  int32_t num_fk_levels;
+  int32_t adj_last_level;
+  int32_t has_device;
+} smplfit_info;
+int smplfit_get_info(const smplfit_handle* h, smplfit_info* info);
+
+/* Introspection of the host tables, for tests.  Copies up to cap int32 entries, sets *n. */
+enum smplfit_table_id {
+  SMPLFIT_TAB_PART_ASSIGNMENT = 0, /* (V)  argmax weight, toes->feet                            */
+  SMPLFIT_TAB_SORT_PERM = 1,       /* (Vp) original index of sorted slot, -1 = padding          */
+  SMPLFIT_TAB_PART_TYPE = 2,       /* (J)  0 none, 1 multi-joint, 2 bone, 3 leaf                */
+  SMPLFIT_TAB_FK_ORDER = 3,        /* joints by tree level (pt/bodyfitter.py:181-192)           */
+  SMPLFIT_TAB_FK_LEVEL_START = 4,  /* (levels+1)                                                */
+  SMPLFIT_TAB_ADJ_FLAG = 5,        /* (J)  1 if refined by the final adjustment                 */
+  SMPLFIT_TAB_USED_PART = 6,       /* (J)  1 if the part's vertices enter the part sums         */
+  SMPLFIT_TAB_SEGMENTS = 7,        /* (nseg,3) start, count, part                               */
+};
+int smplfit_get_table(const smplfit_handle* h, int table_id, int32_t* dst, size_t cap, size_t* n);
+
+/* Bytes of device workspace a call on `batch` instances needs (256-byte aligned base). */
+size_t smplfit_workspace_bytes(const smplfit_handle* h, int batch);
+
+/*
+ * BodyFitter.fit, default configuration (pt/bodyfitter.py:283-549): no share_beta, no scale, no kid,
+ * no warm start.
+ *   target_vertices (B,V,3); target_joints (B,J,3) or NULL; vertex_weights (B,V) or NULL;
+ *   joint_weights (B,J) or NULL.
+ * Outputs: pose_rotvecs (B,3J), shape_betas (B,S), trans (B,3); orientations (B,J,3,3) may be NULL.
+ */
+int smplfit_fit_f32(const smplfit_handle* h, const float* target_vertices,
+                    const float* target_joints, const float* vertex_weights,
+                    const float* joint_weights, int batch, int num_iter, float beta_regularizer,
+                    float beta_regularizer2, int final_adjust_rots, float* pose_rotvecs,
+                    float* shape_betas, float* trans, float* orientations, void* workspace,
+                    size_t workspace_bytes, void* hip_stream);
+
+/*
+ * BodyModel.forward (pt/bodymodel.py:121-307).  Exactly one of pose_rotvecs (B,3J) /
+ * glob_rotmats (B,J,3,3) non-NULL; shape_betas (B,num_betas_given) or NULL; trans (B,3) or NULL.
+ * Outputs: vertices (B,V,3) may be NULL (joints only); joints (B,J,3); orientations (B,J,3,3) may
+ * be NULL.
+ */
+int smplfit_forward_f32(const smplfit_handle* h, const float* pose_rotvecs,
+                        const float* glob_rotmats, const float* shape_betas, int num_betas_given,
+                        const float* trans, int batch, float* vertices, float* joints,
+                        float* orientations, void* workspace, size_t workspace_bytes,
+                        void* hip_stream);
+
+/* Stage entry points for parity tests. */
+
+/* First rotation pass of fit (pt/bodyfitter.py:384-394 -> _fit_global_rotations :1321-1416):
+ * centres the targets, fits every part's global rotation against the template mesh.
+ * glob_rotmats (B,J,3,3) out. */
+int smplfit_part_rotations_f32(const smplfit_handle* h, const float* target_vertices,
+                               const float* target_joints, const float* vertex_weights,
+                               const float* joint_weights, int batch, float* glob_rotmats,
+                               void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* One shape solve (pt/bodyfitter.py:840-1102, _fit_shape -> _fit_shape_gram) for given global
+ * rotations on targets that are centred internally exactly as fit() does; trans is returned
+ * WITHOUT the mean added back.  vertices_out (B,V,3) / joints_out (B,J,3) may be NULL. */
+int smplfit_shape_solve_f32(const smplfit_handle* h, const float* glob_rotmats,
+                            const float* target_vertices, const float* target_joints,
+                            const float* vertex_weights, const float* joint_weights, int batch,
+                            float beta_regularizer, float beta_regularizer2, float* shape_betas,
+                            float* trans, float* vertices_out, float* joints_out, void* workspace,
+                            size_t workspace_bytes, void* hip_stream);
+
+/* Measurement hook (bench.py's roofline leg): launches ONE kernel of the fit `reps` times on
+ * `hip_stream` between two HIP events recorded on that same stream and returns the average
+ * duration in milliseconds.  The workspace must hold the state a preceding smplfit_fit_f32 call on
+ * the same batch left behind.  Synchronises the stream (it is a measurement, not a product call). */
+enum smplfit_kernel_id {
+  SMPLFIT_KERNEL_POSEDIRS_GEMM = 2, /* K2 v_posed = v_template + pose_feature . posedirs          */
+  SMPLFIT_KERNEL_SHAPE_ACCUM = 3,   /* K3 vertex block of the normal equations                    */
+  SMPLFIT_KERNEL_SHAPE_SOLVE = 4,   /* K4 fp64 Cholesky solve                                      */
+  SMPLFIT_KERNEL_LBS_PARTSUM = 5,   /* K5 vertices at the solution + part sums                     */
+};
+int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, int reps,
+                            void* workspace, size_t workspace_bytes, void* hip_stream,
+                            float* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMPLFIT_H_ */

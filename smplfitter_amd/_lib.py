@@ -1,0 +1,195 @@
+"""ctypes binding of ``libsmplfit_hip.so`` (the C-ABI of ``include/smplfit.h``).
+
+The shared library is built in-tree by ``smplfitter_amd.build`` (``hipcc --offload-arch=gfx950``).
+There is NO fallback: if the library is missing or a call fails, an exception is raised — the product
+path never routes through a CPU implementation.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import os.path as osp
+
+import numpy as np
+
+_HERE = osp.dirname(osp.abspath(__file__))
+LIB_PATH = osp.join(_HERE, 'libsmplfit_hip.so')
+
+SMPLFIT_OK = 0
+SMPLFIT_ERR_BAD_ARG = -1
+SMPLFIT_ERR_UNSUPPORTED = -2
+SMPLFIT_ERR_WORKSPACE = -3
+SMPLFIT_ERR_HIP = -4
+SMPLFIT_CREATE_HOST_ONLY = 1
+
+TABLE_IDS = dict(
+    part_assignment=0, sort_perm=1, part_type=2, fk_order=3, fk_level_start=4, adj_flag=5,
+    used_part=6, segments=7,
+)
+
+# every symbol include/smplfit.h declares
+EXPORTED_SYMBOLS = [
+    'smplfit_create', 'smplfit_destroy', 'smplfit_last_error', 'smplfit_version',
+    'smplfit_get_info', 'smplfit_get_table', 'smplfit_workspace_bytes', 'smplfit_fit_f32',
+    'smplfit_forward_f32', 'smplfit_part_rotations_f32', 'smplfit_shape_solve_f32',
+    'smplfit_time_kernel_f32',
+]  # fmt: skip
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ('num_vertices', C.c_int32),
+        ('num_joints', C.c_int32),
+        ('num_betas', C.c_int32),
+        ('is_smpl_family', C.c_int32),
+        ('v_template', _fp),
+        ('shapedirs', _fp),
+        ('posedirs', _fp),
+        ('weights', _fp),
+        ('J_template', _fp),
+        ('J_shapedirs', _fp),
+        ('parents', _ip),
+        ('J_regressor_post_lbs', _fp),
+        ('regressor_num_vertices', C.c_int32),
+    ]
+
+
+class Info(C.Structure):
+    _fields_ = [
+        (n, C.c_int32)
+        for n in (
+            'num_vertices', 'num_joints', 'num_betas', 'padded_vertices', 'num_used_vertices',
+            'skin_width', 'num_segments', 'num_fk_levels', 'adj_last_level', 'has_device',
+        )
+    ]  # fmt: skip
+
+
+class SmplfitError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not osp.exists(LIB_PATH):
+        raise ImportError(
+            f'{LIB_PATH} is missing: build it with `python -m smplfitter_amd.build` '
+            '(hipcc, gfx950).  smplfitter_amd has no CPU fallback.'
+        )
+    lib = C.CDLL(LIB_PATH)
+    vp, sz, i32, f32 = C.c_void_p, C.c_size_t, C.c_int, C.c_float
+    lib.smplfit_create.argtypes = [C.POINTER(ModelDesc), i32, C.POINTER(vp)]
+    lib.smplfit_create.restype = i32
+    lib.smplfit_destroy.argtypes = [vp]
+    lib.smplfit_destroy.restype = None
+    lib.smplfit_last_error.restype = C.c_char_p
+    lib.smplfit_version.restype = C.c_char_p
+    lib.smplfit_get_info.argtypes = [vp, C.POINTER(Info)]
+    lib.smplfit_get_info.restype = i32
+    lib.smplfit_get_table.argtypes = [vp, i32, _ip, sz, C.POINTER(sz)]
+    lib.smplfit_get_table.restype = i32
+    lib.smplfit_workspace_bytes.argtypes = [vp, i32]
+    lib.smplfit_workspace_bytes.restype = sz
+    lib.smplfit_fit_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, sz, vp]
+    lib.smplfit_fit_f32.restype = i32
+    lib.smplfit_forward_f32.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, sz, vp]
+    lib.smplfit_forward_f32.restype = i32
+    lib.smplfit_part_rotations_f32.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, sz, vp]
+    lib.smplfit_part_rotations_f32.restype = i32
+    lib.smplfit_shape_solve_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, vp, vp, sz, vp]
+    lib.smplfit_shape_solve_f32.restype = i32
+    lib.smplfit_time_kernel_f32.argtypes = [vp, i32, i32, i32, vp, sz, vp, C.POINTER(C.c_float)]
+    lib.smplfit_time_kernel_f32.restype = i32
+    _lib = lib
+    return lib
+
+
+def check(status: int):
+    """Map a C-ABI status to the exception types the reference raises for the same condition."""
+    if status == SMPLFIT_OK:
+        return
+    msg = load().smplfit_last_error().decode()
+    if status == SMPLFIT_ERR_BAD_ARG:
+        raise ValueError(msg)
+    if status == SMPLFIT_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise SmplfitError(f'smplfit status {status}: {msg}')
+
+
+def make_desc(v_template, shapedirs, posedirs, weights, J_template, J_shapedirs, parents,
+              J_regressor_post_lbs=None, is_smpl_family=True):
+    """Build a ``ModelDesc`` from numpy arrays; returns (desc, keepalive list)."""
+    f32c = lambda a: np.ascontiguousarray(np.asarray(a), dtype=np.float32)  # noqa: E731
+    arrs = dict(
+        v_template=f32c(v_template), shapedirs=f32c(shapedirs), posedirs=f32c(posedirs),
+        weights=f32c(weights), J_template=f32c(J_template), J_shapedirs=f32c(J_shapedirs),
+    )
+    par = np.ascontiguousarray(np.asarray(parents), dtype=np.int32)
+    V, J = arrs['weights'].shape
+    S = arrs['shapedirs'].shape[2]
+    assert arrs['v_template'].shape == (V, 3)
+    assert arrs['shapedirs'].shape == (V, 3, S)
+    assert arrs['posedirs'].shape == (V, 3, 9 * (J - 1))
+    assert arrs['J_template'].shape == (J, 3) and arrs['J_shapedirs'].shape == (J, 3, S)
+    d = ModelDesc()
+    d.num_vertices, d.num_joints, d.num_betas = V, J, S
+    d.is_smpl_family = 1 if is_smpl_family else 0
+    for k, a in arrs.items():
+        setattr(d, k, a.ctypes.data_as(_fp))
+    d.parents = par.ctypes.data_as(_ip)
+    keep = list(arrs.values()) + [par]
+    if J_regressor_post_lbs is not None:
+        reg = f32c(J_regressor_post_lbs)
+        d.J_regressor_post_lbs = reg.ctypes.data_as(_fp)
+        d.regressor_num_vertices = reg.shape[1]
+        keep.append(reg)
+    else:
+        d.J_regressor_post_lbs = None
+        d.regressor_num_vertices = 0
+    return d, keep
+
+
+class Handle:
+    """Owns a ``smplfit_handle*``."""
+
+    def __init__(self, desc: ModelDesc, host_only: bool = False):
+        lib = load()
+        self._h = C.c_void_p()
+        check(lib.smplfit_create(C.byref(desc), SMPLFIT_CREATE_HOST_ONLY if host_only else 0, C.byref(self._h)))
+        self.info = Info()
+        check(lib.smplfit_get_info(self._h, C.byref(self.info)))
+
+    @property
+    def ptr(self):
+        return self._h
+
+    def table(self, name: str) -> np.ndarray:
+        lib = load()
+        n = C.c_size_t()
+        check(lib.smplfit_get_table(self._h, TABLE_IDS[name], None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.int32)
+        check(lib.smplfit_get_table(self._h, TABLE_IDS[name], out.ctypes.data_as(_ip), n.value, C.byref(n)))
+        return out
+
+    def workspace_bytes(self, batch: int) -> int:
+        return int(load().smplfit_workspace_bytes(self._h, int(batch)))
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            load().smplfit_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,52 @@
+"""Build ``libsmplfit_hip.so`` in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m smplfitter_amd.build [--force]
+"""
+
+from __future__ import annotations
+
+import os
+import os.path as osp
+import shutil
+import subprocess
+import sys
+
+HERE = osp.dirname(osp.abspath(__file__))
+CSRC = osp.join(HERE, 'csrc')
+OUT = osp.join(HERE, 'libsmplfit_hip.so')
+SOURCES = ['smplfit_hip.hip', 'sf_tables.cpp']
+HEADERS = ['sf_math.h', 'sf_stages.h', 'sf_tables.h', '../../include/smplfit.h']
+
+
+def _hipcc():
+    for c in (os.getenv('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if c and osp.exists(c):
+            return c
+    raise RuntimeError('hipcc not found (needed to build libsmplfit_hip.so)')
+
+
+def needs_build():
+    if not osp.exists(OUT):
+        return True
+    t = osp.getmtime(OUT)
+    return any(osp.getmtime(osp.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return OUT
+    cmd = [
+        _hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
+        '-Wno-unused-value',
+        *[osp.join(CSRC, s) for s in SOURCES], '-o', OUT + '.tmp',
+    ]  # fmt: skip
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    os.replace(OUT + '.tmp', OUT)
+    return OUT
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)
+    print(OUT)

@@ -1,0 +1,685 @@
+// Per-instance stages of the fit, written once for two executions:
+//   * on the GPU a workgroup (one 64-lane wave for the joint-level stages) runs a stage
+//     cooperatively: `cx.lane` / `cx.n` stride the loops, `cx.sync()` is the workgroup barrier and all
+//     state that crosses a barrier lives in LDS;
+//   * the host unit-test build (tests/hostemu) runs the very same code with n = 1, sync = no-op.
+// Reference: src/smplfitter/pt/bodyfitter.py (line numbers cited per stage).
+//
+// Normal-equation record ("NE", S betas): [G upper triangle row-major : S(S+1)/2][r : S]
+// [SA per coordinate : 3*S][Sb : 3][W : 1].
+//
+// Per-instance joint block ("jd") handed from the joint stage to the per-vertex kernels, per joint
+// jd_stride(S) floats: [0..8] global rotation R (row-major), [9..11] T0 = P0 - R J0,
+// [12 + c*jd_row(S) + s] T'[c][s] = d(P - R J)/d beta_s.  16-byte aligned rows -> ds_read_b128.
+#pragma once
+#include <stdint.h>
+
+#include "sf_math.h"
+
+namespace sf {
+
+SF_HD constexpr int jd_row(int S) { return (S + 3) / 4 * 4; }
+SF_HD constexpr int jd_stride(int S) {
+  return (12 + 3 * jd_row(S)) % 8 == 4 ? 12 + 3 * jd_row(S) : 12 + 3 * jd_row(S) + 4;
+}
+SF_HD constexpr int ne_ng(int S) { return S * (S + 1) / 2; }
+SF_HD constexpr int ne_size(int S) { return ne_ng(S) + S + 3 * S + 3; }  // W sits at [ne_size]
+SF_HD constexpr int ne_g(int S, int i, int j) { return i * S - i * (i - 1) / 2 + (j - i); }
+
+constexpr int kPsum = 16;  // part-sum record: raw 9, s_t 3, s_a 3, s_w 1
+
+struct alignas(16) F4 {
+  float x, y, z, w;
+};
+SF_HD F4 ld4(const float* p) { return *reinterpret_cast<const F4*>(p); }
+
+// Tables a joint-level stage reads (device or host pointers).
+struct JointTabs {
+  int J, S, num_levels, adj_last_level, P, Kp;
+  const int32_t *parents, *fk_js, *fk_level_start, *cas_start, *cas_flat, *part_type, *toe_src;
+  const int32_t *adj_level_start, *adj_parts;
+  const float *j_ext, *bone_ext;  // (J,3,S+1)
+};
+
+// ---------------------------------------------------------------------------------------------
+// LDS carve for the joint-level stages (floats).
+// ---------------------------------------------------------------------------------------------
+struct JointScratch {
+  float *tj, *rj;  // (J,3) centred target joints / reference joints
+  float *R;        // (J,9) fitted part rotations, later new rotations in the refinement
+  float *G;        // (J,9) global rotations
+  float *P;        // (J,3,S+1) FK positions with beta-Jacobian
+  float *T;        // (J,3,S+1)
+  float *aux;      // (J,3) joints from betas / bones
+  float *pos;      // (J,3)
+  double* dbl;     // solve: NE+1 sums, S*S matrix, S rhs
+};
+SF_HD int joint_scratch_floats(int J, int S) {
+  const int S1 = S + 1;
+  int f = J * 3 * 2 + J * 9 * 2 + J * 3 * S1 * 2 + J * 3 * 2;
+  f = (f + 3) / 4 * 4;
+  return f + 2 * (ne_size(S) + 1 + S * S + S + 4);
+}
+SF_HD JointScratch carve_joint_scratch(float* base, int J, int S) {
+  const int S1 = S + 1;
+  JointScratch s;
+  s.tj = base;
+  s.rj = s.tj + J * 3;
+  s.R = s.rj + J * 3;
+  s.G = s.R + J * 9;
+  s.P = s.G + J * 9;
+  s.T = s.P + J * 3 * S1;
+  s.aux = s.T + J * 3 * S1;
+  s.pos = s.aux + J * 3;
+  int f = J * 3 * 2 + J * 9 * 2 + J * 3 * S1 * 2 + J * 3 * 2;
+  f = (f + 3) / 4 * 4;
+  s.dbl = reinterpret_cast<double*>(base + f);
+  return s;
+}
+
+#define SF_FOR(i, count) for (int i = cx.lane; i < (count); i += cx.n)
+
+// ---------------------------------------------------------------------------------------------
+// Stage J — part rotations (+ optional shape-solve prologue).
+//   rotations: _fit_global_rotations, bodyfitter.py:1321-1416 (buckets :81-97, toes :147-156)
+//   prologue : _fit_shape, bodyfitter.py:869-916 (relative rotations, level-batched FK with the
+//              beta-Jacobian, T = P - G J_ext, pose feature) and the joint block of the normal
+//              equations, _gram_block :1598-1625 called at :1051-1053.
+// psum (J,16): part sums of (target, reference) vertices.  Gprev == nullptr -> identity.
+// ---------------------------------------------------------------------------------------------
+template <class Ctx>
+SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, const float* psum,
+                       const float* tjc, const float* rj_in, const float* Gprev, const float* jw,
+                       bool fit_rotations, bool do_prologue, bool joint_block,
+                       bool joint_block_weighted, float* Gout,
+                       float* rp_out, float* jd_out, float* pext_out, float* gramj_out) {
+  const int J = tb.J, S = tb.S, S1 = S + 1;
+  SF_FOR(k, J * 3) {
+    sh.tj[k] = tjc[k];
+    sh.rj[k] = rj_in ? rj_in[k] : 0.f;
+  }
+  cx.sync();
+  if (!fit_rotations) {  // rotations given by the caller (shape-solve entry point): G = Gprev
+    SF_FOR(k, J * 9) {
+      sh.G[k] = Gprev[k];
+      Gout[k] = Gprev[k];
+    }
+  }
+  SF_FOR(j, J) {
+    if (!fit_rotations) break;
+    const int type = tb.part_type[j];
+    float R[9];
+    m3_identity(R);
+    if (type != 0) {
+      const int c0 = tb.cas_start[j], n = tb.cas_start[j + 1] - c0;
+      // children-mean centres: rows of center_matrix hold 1/n (bodyfitter.py:124-129)
+      const float inv = 1.0f / (float)n;
+      float ct[3] = {0, 0, 0}, ca[3] = {0, 0, 0};
+      for (int q = 0; q < n; ++q) {
+        const int m = tb.cas_flat[c0 + q];
+        for (int c = 0; c < 3; ++c) {
+          ct[c] += inv * sh.tj[m * 3 + c];
+          ca[c] += inv * sh.rj[m * 3 + c];
+        }
+      }
+      float A[9];
+      if (type == 1) {  // multi-joint part: Kabsch on its joints only (:1361-1383)
+        float raw[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, st[3] = {0, 0, 0}, sa[3] = {0, 0, 0}, sw = 0;
+        for (int q = 0; q < n; ++q) {
+          const int m = tb.cas_flat[c0 + q];
+          const float w = jw ? jw[m] : 1.0f;
+          const float* t = sh.tj + m * 3;
+          const float a[3] = {sh.rj[m * 3] * w, sh.rj[m * 3 + 1] * w, sh.rj[m * 3 + 2] * w};
+          for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) raw[r * 3 + c] += t[r] * a[c];
+            st[r] += t[r] * w;
+            sa[r] += a[r];
+          }
+          sw += w;
+        }
+        centered_cov(raw, st, sa, sw, ct, ca, A);
+        proj_so3(A, R);
+      } else {
+        const float* ps = psum + j * kPsum;
+        centered_cov(ps, ps + 9, ps + 12, ps[15], ct, ca, A);
+        if (type == 3) {  // leaf part: Kabsch on its vertices (:1386-1387)
+          proj_so3(A, R);
+        } else {  // bone part: swing + twist (:1389-1412)
+          const int k0 = tb.cas_flat[c0], k1 = tb.cas_flat[c0 + 1];
+          float br[3], bt[3];
+          for (int c = 0; c < 3; ++c) {
+            br[c] = sh.rj[k1 * 3 + c] - sh.rj[k0 * 3 + c];
+            bt[c] = sh.tj[k1 * 3 + c] - sh.tj[k0 * 3 + c];
+          }
+          swing_twist(br, bt, A, R);
+        }
+      }
+    }
+    for (int k = 0; k < 9; ++k) sh.R[j * 9 + k] = R[k];
+  }
+  cx.sync();
+  SF_FOR(j, J) {  // toes take the feet; compose with the previous rotations (:422-433)
+    if (!fit_rotations) break;
+    const int src = tb.toe_src[j] >= 0 ? tb.toe_src[j] : j;
+    float G[9];
+    if (Gprev) {
+      m3_mul(sh.R + src * 9, Gprev + j * 9, G);
+    } else {
+      for (int k = 0; k < 9; ++k) G[k] = sh.R[src * 9 + k];
+    }
+    for (int k = 0; k < 9; ++k) {
+      sh.G[j * 9 + k] = G[k];
+      Gout[j * 9 + k] = G[k];
+    }
+  }
+  cx.sync();
+  if (!do_prologue) return;
+
+  // relative rotations -> pose feature (:869-876, :913); root row of P (:889-891)
+  SF_FOR(j, J) {
+    if (j > 0) {
+      float rel[9];
+      m3_tmul(sh.G + tb.parents[j] * 9, sh.G + j * 9, rel);
+      for (int k = 0; k < 9; ++k) rp_out[(j - 1) * 9 + k] = rel[k];
+    }
+  }
+  SF_FOR(k, tb.Kp - tb.P) rp_out[tb.P + k] = 0.f;
+  SF_FOR(k, 3 * S1) sh.P[k] = tb.j_ext[k];
+  cx.sync();
+  // level-batched FK of positions and their beta-Jacobian (:892-907)
+  for (int lv = 0; lv < tb.num_levels; ++lv) {
+    const int l0 = tb.fk_level_start[lv], nl = tb.fk_level_start[lv + 1] - l0;
+    SF_FOR(idx, nl * S1) {
+      const int j = tb.fk_js[l0 + idx / S1], s = idx % S1, p = tb.parents[j];
+      const float* Gp = sh.G + p * 9;
+      const float* be = tb.bone_ext + j * 3 * S1;
+      const float b0 = be[s], b1 = be[S1 + s], b2 = be[2 * S1 + s];
+      for (int c = 0; c < 3; ++c)
+        sh.P[(j * 3 + c) * S1 + s] =
+            sh.P[(p * 3 + c) * S1 + s] + (Gp[c * 3] * b0 + Gp[c * 3 + 1] * b1 + Gp[c * 3 + 2] * b2);
+    }
+    cx.sync();
+  }
+  // T = P - G J_ext (:909-911); joint block for the vertex kernels; P for the solve stage
+  const int stride = jd_stride(S), row = jd_row(S);
+  SF_FOR(idx, J * S1) {
+    const int j = idx / S1, s = idx % S1;
+    const float* Gj = sh.G + j * 9;
+    const float* je = tb.j_ext + j * 3 * S1;
+    const float e0 = je[s], e1 = je[S1 + s], e2 = je[2 * S1 + s];
+    for (int c = 0; c < 3; ++c) {
+      const float p = sh.P[(j * 3 + c) * S1 + s];
+      const float tv = p - (Gj[c * 3] * e0 + Gj[c * 3 + 1] * e1 + Gj[c * 3 + 2] * e2);
+      pext_out[(j * 3 + c) * S1 + s] = p;
+      if (s == 0)
+        jd_out[j * stride + 9 + c] = tv;
+      else
+        jd_out[j * stride + 12 + c * row + (s - 1)] = tv;
+    }
+  }
+  SF_FOR(idx, J * 9) jd_out[(idx / 9) * stride + idx % 9] = sh.G[idx];
+  SF_FOR(idx, J * 3 * (row - S)) {  // zero the row padding (read, never used, by the vertex kernel)
+    const int j = idx / (3 * (row - S)), r = idx % (3 * (row - S));
+    jd_out[j * stride + 12 + (r / (row - S)) * row + S + r % (row - S)] = 0.f;
+  }
+  // joint block of the normal equations, fp32 sums (:1051-1053, _gram_block :1598-1625)
+  const int NG = ne_ng(S), NE = ne_size(S);
+  SF_FOR(e, NE + 1) {
+    float acc = 0.f;
+    if (joint_block) {
+      if (e < NG) {
+        int i = 0, r = e;
+        while (r >= S - i) {
+          r -= S - i;
+          ++i;
+        }
+        const int jj = i + r;
+        for (int q = 0; q < J * 3; ++q) {
+          const float w = joint_block_weighted ? jw[q / 3] : 1.0f;
+          acc += (w * sh.P[q * S1 + 1 + i]) * sh.P[q * S1 + 1 + jj];
+        }
+      } else if (e < NG + S) {
+        const int i = e - NG;
+        for (int q = 0; q < J * 3; ++q) {
+          const float w = joint_block_weighted ? jw[q / 3] : 1.0f;
+          acc += (w * sh.P[q * S1 + 1 + i]) * (sh.tj[q] - sh.P[q * S1]);
+        }
+      } else if (e < NG + 4 * S) {
+        const int c = (e - NG - S) / S, i = (e - NG - S) % S;
+        for (int j = 0; j < J; ++j) {
+          const float w = joint_block_weighted ? jw[j] : 1.0f;
+          acc += w * sh.P[(j * 3 + c) * S1 + 1 + i];
+        }
+      } else if (e < NE) {
+        const int c = e - NG - 4 * S;
+        for (int j = 0; j < J; ++j) {
+          const float w = joint_block_weighted ? jw[j] : 1.0f;
+          acc += (sh.tj[j * 3 + c] - sh.P[(j * 3 + c) * S1]) * w;
+        }
+      } else {
+        if (joint_block_weighted)
+          for (int j = 0; j < J; ++j) acc += jw[j];
+        else
+          acc = (float)J;
+      }
+    }
+    gramj_out[e] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage S — combine the vertex and joint blocks in fp64, centre, regularise, Cholesky-solve,
+// translation; joints and per-joint skinning translations at the solution.
+//   _fit_shape_gram, bodyfitter.py:1054-1101.
+// gramv: NE+1 doubles (vertex block incl. W), gramj: NE+1 floats (joint block incl. W).
+// Outputs: beta (S), trans (3), rjoints (J,3), jb (J,4) = T0 + T' beta (skinning translation).
+// ---------------------------------------------------------------------------------------------
+template <class Ctx>
+SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, const double* gramv,
+                       const float* gramj, const float* pext, const float* jd, float beta_reg,
+                       float beta_reg2, float* beta_out, float* trans_out, float* rjoints_out,
+                       float* jb_out) {
+  const int J = tb.J, S = tb.S, S1 = S + 1;
+  const int NG = ne_ng(S), NE = ne_size(S);
+  double* sum = sh.dbl;           // NE+1
+  double* M = sum + NE + 1;       // S*S (lower triangle used)
+  double* x = M + S * S;          // S
+  SF_FOR(e, NE + 1) sum[e] = gramv[e] + (double)gramj[e];
+  cx.sync();
+  double W = sum[NE];
+  if (W == 0.0) W = 1.0;  // w_sum_safe (:1060)
+  const double* SA = sum + NG + S;
+  const double* Sb = sum + NG + 4 * S;
+  SF_FOR(idx, S * S) {
+    const int i = idx / S, j = idx % S;
+    if (j <= i) {  // lower triangle: M[i][j] = G[j][i] - sum_c SA[c][i] SA[c][j] / W (+ lambda)
+      double g = sum[ne_g(S, j, i)];
+      g -= (SA[i] * SA[j] + SA[S + i] * SA[S + j] + SA[2 * S + i] * SA[2 * S + j]) / W;
+      if (i == j) g += (double)(i < 2 ? beta_reg2 : beta_reg);  // (:1064-1071)
+      M[i * S + j] = g;
+    }
+  }
+  SF_FOR(i, S)
+  x[i] = sum[NG + i] - (SA[i] * Sb[0] + SA[S + i] * Sb[1] + SA[2 * S + i] * Sb[2]) / W;
+  cx.sync();
+  // in-place Cholesky M = L L^T (:1083), column by column
+  for (int k = 0; k < S; ++k) {
+    if (cx.lane == 0) M[k * S + k] = sqrt(M[k * S + k]);
+    cx.sync();
+    SF_FOR(i, S) if (i > k) M[i * S + k] /= M[k * S + k];
+    cx.sync();
+    SF_FOR(idx, S * S) {
+      const int i = idx / S, j = idx % S;
+      if (j > k && i >= j) M[i * S + j] -= M[i * S + k] * M[j * S + k];
+    }
+    cx.sync();
+  }
+  if (cx.lane == 0) {  // forward / back substitution (:1084)
+    for (int i = 0; i < S; ++i) {
+      double v = x[i];
+      for (int k = 0; k < i; ++k) v -= M[i * S + k] * x[k];
+      x[i] = v / M[i * S + i];
+    }
+    for (int i = S - 1; i >= 0; --i) {
+      double v = x[i];
+      for (int k = i + 1; k < S; ++k) v -= M[k * S + i] * x[k];
+      x[i] = v / M[i * S + i];
+    }
+  }
+  cx.sync();
+  // translation (:1086-1088) and outputs, cast to fp32 (:1088-1089)
+  float* betaf = sh.aux;       // reuse (S <= 3J)
+  float* transf = sh.aux + S;  // 3
+  SF_FOR(i, S) {
+    betaf[i] = (float)x[i];
+    beta_out[i] = (float)x[i];
+  }
+  SF_FOR(c, 3) {
+    double v = Sb[c] / W;
+    for (int i = 0; i < S; ++i) v -= (SA[c * S + i] / W) * x[i];
+    transf[c] = (float)v;
+    trans_out[c] = (float)v;
+  }
+  cx.sync();
+  const int stride = jd_stride(S), row = jd_row(S);
+  SF_FOR(idx, J * 3) {
+    const int j = idx / 3, c = idx % 3;
+    // joints = P0 + P' beta + trans (:1093-1098)
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += pext[idx * S1 + 1 + s] * betaf[s];
+    rjoints_out[idx] = pext[idx * S1] + acc + transf[c];
+    // skinning translation at the solution, T0 + T' beta (vertex re-evaluation :1099-1101)
+    float tb0 = 0.f;
+    const float* tr = jd + j * stride + 12 + c * row;
+    for (int s = 0; s < S; ++s) tb0 += tr[s] * betaf[s];
+    jb_out[j * 4 + c] = jd[j * stride + 9 + c] + tb0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage R — dependent rotation refinement, level-batched branch (bodyfitter.py:1418-1544) and the
+// epilogue (:513-539): trans += mean, relative rotations, mat2rotvec.
+//   psum: part sums of (target, final reference vertices); rj_true: joints of the final solve.
+//   rj_reg/tj: joints entering the joint term (equal to rj_true / target joints when joints are
+//   given; regressed ones otherwise, :1433-1438).
+// ---------------------------------------------------------------------------------------------
+template <class Ctx>
+SF_HD void refine_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, const float* psum,
+                        const float* tj_in, const float* rj_joint_term, const float* rj_true,
+                        const float* jw, const float* Gprev, const float* beta, const float* trans,
+                        const float* mean, bool final_adjust, float* pose_out, float* beta_out,
+                        float* trans_out, float* orient_out) {
+  const int J = tb.J, S = tb.S, S1 = S + 1;
+  SF_FOR(k, J * 9) {
+    sh.G[k] = Gprev[k];
+    sh.R[k] = Gprev[k];
+  }
+  if (final_adjust) {
+    SF_FOR(k, J * 3) {
+      sh.tj[k] = tj_in[k];
+      sh.rj[k] = rj_joint_term[k];
+      // joints from betas (:1441-1445)
+      float acc = 0.f;
+      for (int s = 0; s < S; ++s) acc += tb.j_ext[k * S1 + 1 + s] * beta[s];
+      sh.aux[k] = tb.j_ext[k * S1] + acc;
+    }
+    cx.sync();
+    SF_FOR(k, J * 3) {  // bones (:1452-1460) into T (scratch), root position (:1481)
+      const int j = k / 3, c = k % 3;
+      sh.T[k] = sh.aux[k] - (j > 0 ? sh.aux[tb.parents[j] * 3 + c] : 0.f);
+      if (j == 0) sh.pos[k] = sh.aux[k] + trans[c];
+    }
+    cx.sync();
+    for (int lv = 0; lv <= tb.adj_last_level; ++lv) {
+      const int l0 = tb.fk_level_start[lv], nl = tb.fk_level_start[lv + 1] - l0;
+      SF_FOR(q, nl) {  // FK of this level from final parents (:1491-1498)
+        const int j = tb.fk_js[l0 + q], p = tb.parents[j];
+        float rb[3];
+        m3_vec(sh.R + p * 9, sh.T + j * 3, rb);
+        for (int c = 0; c < 3; ++c) sh.pos[j * 3 + c] = sh.pos[p * 3 + c] + rb[c];
+      }
+      cx.sync();
+      const int a0 = tb.adj_level_start[lv], na = tb.adj_level_start[lv + 1] - a0;
+      SF_FOR(q, na) {  // refine the adjustable parts of the level (:1505-1537)
+        const int i = tb.adj_parts[a0 + q];
+        const float* ct = sh.pos + i * 3;
+        const float* ca = rj_true + i * 3;
+        const float* ps = psum + i * kPsum;
+        float A[9];
+        centered_cov(ps, ps + 9, ps + 12, ps[15], ct, ca, A);
+        for (int m0 = tb.cas_start[i]; m0 < tb.cas_start[i + 1]; ++m0) {
+          const int m = tb.cas_flat[m0];
+          const float w = jw ? jw[m] : 1.0f;
+          float est[3], dfl[3];
+          for (int c = 0; c < 3; ++c) {
+            est[c] = sh.tj[m * 3 + c] - ct[c];
+            dfl[c] = (sh.rj[m * 3 + c] - ca[c]) * w;
+          }
+          for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) A[r * 3 + c] += est[r] * dfl[c];
+        }
+        float Rf[9], Rn[9];
+        proj_so3(A, Rf);
+        m3_mul(Rf, sh.G + i * 9, Rn);
+        for (int k = 0; k < 9; ++k) sh.R[i * 9 + k] = Rn[k];
+      }
+      cx.sync();
+    }
+    SF_FOR(j, J) {  // toes copy the feet (:1539-1543)
+      if (tb.toe_src[j] >= 0)
+        for (int k = 0; k < 9; ++k) sh.R[j * 9 + k] = sh.R[tb.toe_src[j] * 9 + k];
+    }
+  }
+  cx.sync();
+  SF_FOR(j, J) {  // relative rotations and log map (:523-539)
+    float rel[9];
+    if (j > 0) {
+      m3_tmul(sh.R + tb.parents[j] * 9, sh.R + j * 9, rel);
+    } else {
+      for (int k = 0; k < 9; ++k) rel[k] = sh.R[k];
+    }
+    float rv[3];
+    mat2rotvec(rel, rv);
+    for (int c = 0; c < 3; ++c) pose_out[j * 3 + c] = rv[c];
+    if (orient_out)
+      for (int k = 0; k < 9; ++k) orient_out[j * 9 + k] = sh.R[j * 9 + k];
+  }
+  SF_FOR(i, S) beta_out[i] = beta[i];
+  SF_FOR(c, 3) trans_out[c] = trans[c] + mean[c];  // (:519)
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage F — forward-kinematics prologue of BodyModel.forward (bodymodel.py:216-284): rotations from
+// rotvecs (or given global rotations), joints from betas, FK, pose feature and per-joint skinning
+// translations T = pos - G j (+ trans folded in by the vertex kernel).
+// ---------------------------------------------------------------------------------------------
+template <class Ctx>
+SF_HD void forward_joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh,
+                               const float* pose_rotvecs, const float* glob_in, const float* betas,
+                               int nb, const float* trans, float* rp_out, float* jd_out,
+                               float* joints_out, float* orient_out) {
+  const int J = tb.J, S = tb.S, S1 = S + 1;
+  if (glob_in) {
+    SF_FOR(k, J * 9) sh.G[k] = glob_in[k];
+  } else {
+    SF_FOR(j, J) {
+      float m[9];
+      if (pose_rotvecs) {
+        rotvec2mat(pose_rotvecs + j * 3, m);
+      } else {
+        m3_identity(m);
+      }
+      for (int k = 0; k < 9; ++k) sh.R[j * 9 + k] = m[k];
+    }
+    cx.sync();
+    if (cx.lane == 0)
+      for (int k = 0; k < 9; ++k) sh.G[k] = sh.R[k];
+    cx.sync();
+    // sequential FK of rotations (bodymodel.py:230-234), one level at a time
+    for (int lv = 0; lv < tb.num_levels; ++lv) {
+      const int l0 = tb.fk_level_start[lv], nl = tb.fk_level_start[lv + 1] - l0;
+      SF_FOR(q, nl) {
+        const int j = tb.fk_js[l0 + q];
+        float g[9];
+        m3_mul(sh.G + tb.parents[j] * 9, sh.R + j * 9, g);
+        for (int k = 0; k < 9; ++k) sh.G[j * 9 + k] = g[k];
+      }
+      cx.sync();
+    }
+  }
+  cx.sync();
+  SF_FOR(k, J * 3) {  // joints from betas (bodymodel.py:258-264)
+    float acc = 0.f;
+    for (int s = 0; s < nb; ++s) acc += tb.j_ext[k * S1 + 1 + s] * betas[s];
+    sh.aux[k] = tb.j_ext[k * S1] + acc;
+  }
+  SF_FOR(j, J) {  // pose feature (bodymodel.py:244-251, :286)
+    if (j > 0) {
+      float rel[9];
+      if (glob_in) {
+        m3_tmul(sh.G + tb.parents[j] * 9, sh.G + j * 9, rel);
+      } else {
+        for (int k = 0; k < 9; ++k) rel[k] = sh.R[j * 9 + k];
+      }
+      for (int k = 0; k < 9; ++k) rp_out[(j - 1) * 9 + k] = rel[k];
+    }
+  }
+  SF_FOR(k, tb.Kp - tb.P) rp_out[tb.P + k] = 0.f;
+  cx.sync();
+  SF_FOR(c, 3) sh.pos[c] = sh.aux[c];
+  cx.sync();
+  for (int lv = 0; lv < tb.num_levels; ++lv) {  // FK of positions (bodymodel.py:266-275)
+    const int l0 = tb.fk_level_start[lv], nl = tb.fk_level_start[lv + 1] - l0;
+    SF_FOR(q, nl) {
+      const int j = tb.fk_js[l0 + q], p = tb.parents[j];
+      const float bone[3] = {sh.aux[j * 3] - sh.aux[p * 3], sh.aux[j * 3 + 1] - sh.aux[p * 3 + 1],
+                             sh.aux[j * 3 + 2] - sh.aux[p * 3 + 2]};
+      float rb[3];
+      m3_vec(sh.G + p * 9, bone, rb);
+      for (int c = 0; c < 3; ++c) sh.pos[j * 3 + c] = sh.pos[p * 3 + c] + rb[c];
+    }
+    cx.sync();
+  }
+  const int stride = jd_stride(S);
+  SF_FOR(j, J) {  // translations = pos - G j (bodymodel.py:297)
+    float gj[3];
+    m3_vec(sh.G + j * 9, sh.aux + j * 3, gj);
+    for (int c = 0; c < 3; ++c) {
+      jd_out[j * stride + 9 + c] = sh.pos[j * 3 + c] - gj[c];
+      joints_out[j * 3 + c] = sh.pos[j * 3 + c] + (trans ? trans[c] : 0.f);
+    }
+    for (int k = 0; k < 9; ++k) {
+      jd_out[j * stride + k] = sh.G[j * 9 + k];
+      if (orient_out) orient_out[j * 9 + k] = sh.G[j * 9 + k];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-vertex bodies (lane = vertex).  jd = the instance's joint block (LDS on the GPU).
+// ---------------------------------------------------------------------------------------------
+template <int KW>
+struct Skin {
+  int j[KW];
+  float w[KW];
+};
+
+template <int KW>
+SF_HD Skin<KW> load_skin(const uint32_t* widx, const float* wval, int Vp, int i) {
+  Skin<KW> s;
+#pragma unroll
+  for (int q = 0; q < KW / 4; ++q) {
+    const uint32_t u = widx[(size_t)q * Vp + i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s.j[q * 4 + k] = (int)((u >> (8 * k)) & 0xffu);
+  }
+#pragma unroll
+  for (int k = 0; k < KW; ++k) s.w[k] = wval[(size_t)k * Vp + i];
+  return s;
+}
+
+// blended rotation and (optionally) translation from 3 F4 per joint: R0..R8, T0
+template <int S, int KW>
+SF_HD void blend_rt(const float* jd, const Skin<KW>& sk, float* Rt, float* T0) {
+  constexpr int STRIDE = jd_stride(S);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Rt[k] = 0.f;
+  T0[0] = T0[1] = T0[2] = 0.f;
+#pragma unroll
+  for (int k = 0; k < KW; ++k) {
+    const float* p = jd + sk.j[k] * STRIDE;
+    const F4 a = ld4(p), b = ld4(p + 4), c = ld4(p + 8);
+    const float w = sk.w[k];
+    Rt[0] += w * a.x; Rt[1] += w * a.y; Rt[2] += w * a.z; Rt[3] += w * a.w;
+    Rt[4] += w * b.x; Rt[5] += w * b.y; Rt[6] += w * b.z; Rt[7] += w * b.w;
+    Rt[8] += w * c.x; T0[0] += w * c.y; T0[1] += w * c.z; T0[2] += w * c.w;
+  }
+}
+
+// Normal-equation accumulation of one vertex (_fit_shape_gram, bodyfitter.py:999-1048):
+//   Rt = sum_j w_j G_j;  pos = Rt v_posed + sum_j w_j T0_j;  b = t - pos
+//   Jac[c][s] = Rt[c][:] . shapedirs[:, s] + sum_j w_j T'_j[c][s]
+//   G += w Jac^T Jac, r += w Jac^T b, SA[c] += w Jac[c], Sb[c] += w b[c]
+// sdv: the vertex's shapedirs, [c'*S + s].  acc: NE floats (W is handled by the caller).
+template <int S, int KW, bool WEIGHTED>
+SF_HD void shape_accum_vertex(const float* jd, const Skin<KW>& sk, const float* vp,
+                              const float* tv, const float* sdv, float wv, float* acc) {
+  constexpr int STRIDE = jd_stride(S), ROW = jd_row(S), NG = ne_ng(S);
+  float Rt[9], T0[3];
+  blend_rt<S, KW>(jd, sk, Rt, T0);
+  float b[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float pos = (Rt[c * 3] * vp[0] + Rt[c * 3 + 1] * vp[1] + Rt[c * 3 + 2] * vp[2]) + T0[c];
+    b[c] = tv[c] - pos;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float a[ROW];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+      a[s] = Rt[c * 3] * sdv[s] + Rt[c * 3 + 1] * sdv[S + s] + Rt[c * 3 + 2] * sdv[2 * S + s];
+#pragma unroll
+    for (int s = S; s < ROW; ++s) a[s] = 0.f;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+      const float* p = jd + sk.j[k] * STRIDE + 12 + c * ROW;
+      const float w = sk.w[k];
+#pragma unroll
+      for (int q = 0; q < ROW / 4; ++q) {
+        const F4 t = ld4(p + 4 * q);
+        a[4 * q] += w * t.x; a[4 * q + 1] += w * t.y; a[4 * q + 2] += w * t.z; a[4 * q + 3] += w * t.w;
+      }
+    }
+    const float bc = WEIGHTED ? wv * b[c] : b[c];
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+      const float wa = WEIGHTED ? wv * a[i] : a[i];
+#pragma unroll
+      for (int j = i; j < S; ++j) acc[ne_g(S, i, j)] += wa * a[j];
+      acc[NG + i] += wa * b[c];
+      acc[NG + S + c * S + i] += wa;
+    }
+    acc[NG + 4 * S + c] += bc;
+  }
+}
+
+// Vertex at the solved shape (bodyfitter.py:1099-1101; LBS of bodymodel.py:288-306):
+//   v = Rt (v_posed + shapedirs beta) + sum_j w_j jb_j (+ trans)
+// jb: (J,4) per-joint skinning translation at the solution.
+template <int S, int KW>
+SF_HD void lbs_vertex(const float* jd, const float* jb, const Skin<KW>& sk, const float* vp,
+                      const float* sdv, const float* beta, int nb, const float* trans,
+                      float* out) {
+  constexpr int STRIDE = jd_stride(S);
+  float Rt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Tb[3] = {0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < KW; ++k) {
+    const float* p = jd + sk.j[k] * STRIDE;
+    const F4 a = ld4(p), b = ld4(p + 4);
+    const float r8 = p[8];
+    const F4 t = ld4(jb + sk.j[k] * 4);
+    const float w = sk.w[k];
+    Rt[0] += w * a.x; Rt[1] += w * a.y; Rt[2] += w * a.z; Rt[3] += w * a.w;
+    Rt[4] += w * b.x; Rt[5] += w * b.y; Rt[6] += w * b.z; Rt[7] += w * b.w;
+    Rt[8] += w * r8;
+    Tb[0] += w * t.x; Tb[1] += w * t.y; Tb[2] += w * t.z;
+  }
+  float vs[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float acc = 0.f;
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+      if (s < nb) acc += sdv[c * S + s] * beta[s];
+    vs[c] = vp[c] + acc;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    out[c] = (Rt[c * 3] * vs[0] + Rt[c * 3 + 1] * vs[1] + Rt[c * 3 + 2] * vs[2]) + Tb[c] +
+             trans[c];
+}
+
+// Part-sum accumulation of one vertex (_part_sums, bodyfitter.py:257-280): acc is a kPsum record.
+SF_HD void partsum_vertex(const float* t, const float* a_in, float w, bool weighted, float* acc) {
+  float a[3] = {a_in[0], a_in[1], a_in[2]};
+  float ts[3] = {t[0], t[1], t[2]};
+  if (weighted) {
+    for (int c = 0; c < 3; ++c) {
+      a[c] *= w;
+      ts[c] *= w;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[r * 3 + c] += t[r] * a[c];
+    acc[9 + r] += ts[r];
+    acc[12 + r] += a[r];
+  }
+  acc[15] += weighted ? w : 1.0f;
+}
+
+#undef SF_FOR
+
+}  // namespace sf

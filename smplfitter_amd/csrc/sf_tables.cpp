@@ -1,0 +1,254 @@
+// Host table builder — see sf_tables.h.  Reference: src/smplfitter/pt/bodyfitter.py:25-233.
+#include "sf_tables.h"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace sf {
+
+static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsupported) {
+  *unsupported = false;
+  if (!d.v_template || !d.shapedirs || !d.posedirs || !d.weights || !d.J_template ||
+      !d.J_shapedirs || !d.parents)
+    return "smplfit_create: null model array";
+  if (d.num_vertices <= 0 || d.num_joints <= 1 || d.num_betas <= 0)
+    return "smplfit_create: bad model dimensions";
+  const int V = d.num_vertices, J = d.num_joints, S = d.num_betas;
+  if (J > kMaxJoints) {
+    *unsupported = true;
+    return "smplfit_create: more than 64 joints is not supported";
+  }
+  if (S < 2) {
+    *unsupported = true;
+    return "smplfit_create: num_betas < 2 is not supported";
+  }
+  t.V = V; t.J = J; t.S = S; t.P = 9 * (J - 1);
+  t.Vp = round_up(V, kVertexPad);
+  t.Kp = round_up(t.P, kGemmKPad);
+  t.smpl_family = d.is_smpl_family != 0;
+  if (t.smpl_family && J < 12) return "smplfit_create: smpl-family model with < 12 joints";
+
+  // ---- kinematic tree: parents, levels (bodyfitter.py:181-192), children-and-self (:61-64) ----
+  t.parents.assign(J, 0);
+  for (int i = 1; i < J; ++i) {
+    int p = d.parents[i];
+    if (p < 0 || p >= i) return "smplfit_create: parents must satisfy 0 <= parents[i] < i";
+    t.parents[i] = p;
+  }
+  std::vector<int> depth(J, 0);
+  int max_depth = 0;
+  for (int i = 1; i < J; ++i) {
+    depth[i] = depth[t.parents[i]] + 1;
+    max_depth = std::max(max_depth, depth[i]);
+  }
+  t.fk_js.clear();
+  t.fk_level_start.assign(1, 0);
+  for (int lv = 1; lv <= max_depth; ++lv) {
+    for (int i = 0; i < J; ++i)
+      if (depth[i] == lv) t.fk_js.push_back(i);
+    t.fk_level_start.push_back((int)t.fk_js.size());
+  }
+  std::vector<std::vector<int>> cas(J);
+  for (int i = 0; i < J; ++i) cas[i].push_back(i);
+  for (int i = 1; i < J; ++i) cas[t.parents[i]].push_back(i);
+  t.cas_start.assign(1, 0);
+  t.cas_flat.clear();
+  for (int i = 0; i < J; ++i) {
+    for (int j : cas[i]) t.cas_flat.push_back(j);
+    t.cas_start.push_back((int)t.cas_flat.size());
+  }
+
+  // ---- part buckets (:81-97), toe copies (:147-156), adjustable parts (:101-104) ----
+  t.part_type.assign(J, kPartNone);
+  t.toe_src.assign(J, -1);
+  for (int i = 0; i < J; ++i) {
+    if (t.smpl_family && (i == 10 || i == 11)) {
+      t.toe_src[i] = i - 3;  // 10 <- 7, 11 <- 8
+      continue;
+    }
+    int n = (int)cas[i].size();
+    t.part_type[i] = n >= 3 ? kPartMulti : (n == 2 ? kPartBone : kPartLeaf);
+  }
+  t.adj_flag.assign(J, 0);
+  if (t.smpl_family) {
+    static const int adj[] = {1, 2, 4, 5, 7, 8, 16, 17, 18, 19};
+    for (int a : adj)
+      if (a < J) t.adj_flag[a] = 1;
+    // level-batched refinement requires every adjustable part to hold the same number of joints
+    // (bodyfitter.py:219-221); true for SMPL / SMPL-X / SMPL+H.
+    int n0 = -1;
+    for (int i = 0; i < J; ++i)
+      if (t.adj_flag[i]) {
+        if (n0 < 0) n0 = (int)cas[i].size();
+        if ((int)cas[i].size() != n0) {
+          *unsupported = true;
+          return "smplfit_create: adjustable parts with differing joint counts (sequential "
+                 "fallback of the reference, bodyfitter.py:1546-1595, is not implemented)";
+        }
+      }
+  } else {
+    *unsupported = true;
+    return "smplfit_create: non-SMPL-family models (MANO/FLAME) use the reference's sequential "
+           "refinement, which is not implemented";
+  }
+  t.adj_level_start.assign(1, 0);
+  t.adj_parts.clear();
+  t.adj_last_level = -1;
+  for (int lv = 0; lv < t.num_levels(); ++lv) {
+    for (int k = t.fk_level_start[lv]; k < t.fk_level_start[lv + 1]; ++k)
+      if (t.adj_flag[t.fk_js[k]]) {
+        t.adj_parts.push_back(t.fk_js[k]);
+        t.adj_last_level = lv;
+      }
+    t.adj_level_start.push_back((int)t.adj_parts.size());
+  }
+  t.used_part.assign(J, 0);
+  for (int i = 0; i < J; ++i)
+    if (t.part_type[i] == kPartBone || t.part_type[i] == kPartLeaf || t.adj_flag[i])
+      t.used_part[i] = 1;
+
+  // ---- part assignment = argmax skinning weight, toes -> feet (:36-44) ----
+  t.part_assignment.assign(V, 0);
+  int max_nnz = 0;
+  for (int v = 0; v < V; ++v) {
+    const float* w = d.weights + (size_t)v * J;
+    int best = 0, nnz = 0;
+    for (int j = 0; j < J; ++j) {
+      if (w[j] > w[best]) best = j;  // first maximum, like argmax
+      if (w[j] != 0.f) ++nnz;
+    }
+    if (t.smpl_family && (best == 10 || best == 11)) best -= 3;
+    t.part_assignment[v] = best;
+    max_nnz = std::max(max_nnz, nnz);
+  }
+  if (max_nnz > 8) {
+    *unsupported = true;
+    return "smplfit_create: more than 8 non-zero skinning weights per vertex";
+  }
+  t.KW = max_nnz <= 4 ? 4 : 8;
+
+  // ---- sorted slots: used parts first (by part id, stable), then the rest ----
+  std::vector<int> order(V);
+  std::iota(order.begin(), order.end(), 0);
+  auto key = [&](int v) {
+    int p = t.part_assignment[v];
+    return (t.used_part[p] ? 0 : kMaxJoints) + p;
+  };
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key(a) < key(b); });
+  const int Vp = t.Vp;
+  t.perm.assign(Vp, -1);
+  t.slot_part.assign(Vp, -1);
+  t.n_used = 0;
+  for (int i = 0; i < V; ++i) {
+    t.perm[i] = order[i];
+    t.slot_part[i] = t.part_assignment[order[i]];
+    if (t.used_part[t.slot_part[i]]) t.n_used = i + 1;
+  }
+  t.segments.clear();
+  for (int i = 0; i < t.n_used;) {
+    int p = t.slot_part[i], e = i;
+    while (e < t.n_used && t.slot_part[e] == p) ++e;
+    for (int s = i; s < e; s += kTile) t.segments.push_back({s, std::min(kTile, e - s), p});
+    i = e;
+  }
+
+  // ---- per-slot constants ----
+  const int P = t.P;
+  t.vt.assign((size_t)3 * Vp, 0.f);
+  t.dm.assign((size_t)3 * Vp, 0.f);
+  t.sd.assign((size_t)3 * S * Vp, 0.f);
+  t.widx.assign((size_t)(t.KW / 4) * Vp, 0u);
+  t.wval.assign((size_t)t.KW * Vp, 0.f);
+  t.pdT.assign((size_t)t.Kp * 3 * Vp, 0.f);
+  for (int i = 0; i < V; ++i) {
+    const int v = order[i];
+    const float* w = d.weights + (size_t)v * J;
+    float wsum = 0.f;  // blended identity rotation = sum of weights (bodymodel.py:297-306)
+    int k = 0;
+    for (int j = 0; j < J; ++j) {
+      wsum += w[j];
+      if (w[j] != 0.f) {
+        t.widx[(size_t)(k / 4) * Vp + i] |= (uint32_t)j << (8 * (k % 4));
+        t.wval[(size_t)k * Vp + i] = w[j];
+        ++k;
+      }
+    }
+    // padded pairs keep weight 0 and point at the vertex's own part (an LDS address other lanes
+    // of the wave already read -> broadcast)
+    for (; k < t.KW; ++k)
+      t.widx[(size_t)(k / 4) * Vp + i] |= (uint32_t)t.part_assignment[v] << (8 * (k % 4));
+    for (int c = 0; c < 3; ++c) {
+      const float vtc = d.v_template[(size_t)v * 3 + c];
+      t.vt[(size_t)c * Vp + i] = vtc;
+      const float* pd = d.posedirs + ((size_t)v * 3 + c) * P;
+      // default mesh: v_posed at identity rotations (feature = vec(I) per joint), times sum(w)
+      float acc = vtc;
+      for (int p = 0; p < P; ++p) {
+        t.pdT[(size_t)p * 3 * Vp + (size_t)c * Vp + i] = pd[p];
+        if (p % 9 == 0 || p % 9 == 4 || p % 9 == 8) acc += pd[p];
+      }
+      t.dm[(size_t)c * Vp + i] = wsum * acc;
+      for (int s = 0; s < S; ++s)
+        t.sd[(size_t)(c * S + s) * Vp + i] = d.shapedirs[((size_t)v * 3 + c) * S + s];
+    }
+  }
+  t.vtN = t.vt;
+
+  // ---- per-joint constants (:52-58, :191-192) ----
+  const int S1 = S + 1;
+  t.j_ext.assign((size_t)J * 3 * S1, 0.f);
+  t.bone_ext.assign((size_t)J * 3 * S1, 0.f);
+  for (int j = 0; j < J; ++j)
+    for (int c = 0; c < 3; ++c) {
+      t.j_ext[((size_t)j * 3 + c) * S1] = d.J_template[j * 3 + c];
+      for (int s = 0; s < S; ++s)
+        t.j_ext[((size_t)j * 3 + c) * S1 + 1 + s] = d.J_shapedirs[((size_t)j * 3 + c) * S + s];
+    }
+  for (int j = 0; j < J; ++j)
+    for (int k = 0; k < 3 * S1; ++k)
+      t.bone_ext[(size_t)j * 3 * S1 + k] =
+          t.j_ext[(size_t)j * 3 * S1 + k] - t.j_ext[(size_t)t.parents[j] * 3 * S1 + k];
+
+  // template-pass part sums of the reference side (s_a, s_w of _part_sums with a = default mesh)
+  t.sa0.assign((size_t)J * 3, 0.f);
+  t.sw0.assign(J, 0.f);
+  {
+    std::vector<double> acc((size_t)J * 3, 0.0);
+    for (int i = 0; i < t.n_used; ++i) {
+      int p = t.slot_part[i];
+      for (int c = 0; c < 3; ++c) acc[p * 3 + c] += t.dm[(size_t)c * Vp + i];
+      t.sw0[p] += 1.f;
+    }
+    for (size_t k = 0; k < acc.size(); ++k) t.sa0[k] = (float)acc[k];
+  }
+
+  // ---- sparse joint regressor over sorted slots ----
+  t.has_regressor = false;
+  t.reg_start.assign(1, 0);
+  t.reg_slot.clear();
+  t.reg_val.clear();
+  if (d.J_regressor_post_lbs && d.regressor_num_vertices == V) {
+    std::vector<int> slot_of(V);
+    for (int i = 0; i < V; ++i) slot_of[order[i]] = i;
+    for (int j = 0; j < J; ++j) {
+      std::vector<std::pair<int, float>> row;
+      for (int v = 0; v < V; ++v) {
+        float r = d.J_regressor_post_lbs[(size_t)j * V + v];
+        if (r != 0.f) row.push_back({slot_of[v], r});
+      }
+      std::sort(row.begin(), row.end());
+      for (auto& e : row) {
+        t.reg_slot.push_back(e.first);
+        t.reg_val.push_back(e.second);
+      }
+      t.reg_start.push_back((int)t.reg_slot.size());
+    }
+    t.has_regressor = true;
+  }
+  return "";
+}
+
+}  // namespace sf

@@ -1,0 +1,82 @@
+// Host-side tables derived from a body model: the native counterpart of BodyFitter.__init__
+// (reference src/smplfitter/pt/bodyfitter.py:25-233), emitted in the layouts the HIP kernels read.
+//
+// Layout decisions:
+//  * vertices are re-ordered ("sorted slots") by body part — used parts first, in part order — so a
+//    64-lane wave tile belongs to ONE part (wave-level segmented sums, LDS broadcasts of joint data)
+//    and every per-vertex constant is stored SoA over sorted slots, padded to Vp (multiple of 128);
+//  * skinning weights are kept sparse: KW (4 or 8) (joint, weight) pairs per vertex;
+//  * posedirs is stored K-major [Kp][3*Vp] (n = c*Vp + slot) for the fp32 MFMA GEMM.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/smplfit.h"
+
+namespace sf {
+
+constexpr int kMaxJoints = 64;
+constexpr int kTile = 64;        // wave width
+constexpr int kVertexPad = 128;  // Vp granularity (GEMM N tile = 128 divides 3*Vp)
+constexpr int kGemmKPad = 16;    // posedirs K padded to the GEMM K step
+constexpr int kJdStride = 52;    // floats per joint in the per-instance joint block (see sf_stages.h)
+
+enum PartType : int32_t { kPartNone = 0, kPartMulti = 1, kPartBone = 2, kPartLeaf = 3 };
+
+struct Segment {
+  int32_t start, count, part;
+};
+
+struct HostTables {
+  int V = 0, J = 0, S = 0, P = 0;
+  int Vp = 0, Kp = 0, KW = 4;
+  bool smpl_family = false;
+  bool has_regressor = false;
+
+  // kinematic tree
+  std::vector<int32_t> parents;         // (J) parents[0] = 0 here ("parents_with_root")
+  std::vector<int32_t> fk_js;           // joints of levels 1.. concatenated
+  std::vector<int32_t> fk_level_start;  // (L+1) offsets into fk_js
+  std::vector<int32_t> cas_start, cas_flat;  // children-and-self lists
+  std::vector<int32_t> part_type;       // (J)
+  std::vector<int32_t> toe_src;         // (J) copy-from part or -1
+  std::vector<int32_t> adj_flag;        // (J)
+  std::vector<int32_t> adj_level_start, adj_parts;  // adjustable parts per level (levels as fk)
+  int adj_last_level = -1;
+  std::vector<int32_t> used_part;       // (J)
+
+  // vertex ordering
+  std::vector<int32_t> part_assignment;  // (V) original order
+  std::vector<int32_t> perm;             // (Vp) original index of sorted slot, -1 padding
+  std::vector<int32_t> slot_part;        // (Vp) part of sorted slot, -1 padding
+  int n_used = 0;                        // slots [0, n_used) belong to used parts
+  std::vector<Segment> segments;         // part-aligned tiles over [0, n_used)
+
+  // per-slot constants (SoA over Vp)
+  std::vector<float> vt;        // (3,Vp)  v_template
+  std::vector<float> dm;        // (3,Vp)  default mesh = forward(zero pose, zero betas)
+  std::vector<float> sd;        // (3*S,Vp) shapedirs, row index c*S+s
+  std::vector<uint32_t> widx;   // (KW/4, Vp) 4 joint ids per word, byte k = k-th pair
+  std::vector<float> wval;      // (KW, Vp)
+  std::vector<float> pdT;       // (Kp, 3*Vp) posedirs, K-major
+  std::vector<float> vtN;       // (3*Vp) v_template in GEMM column order (== vt flattened)
+
+  // per-joint constants
+  std::vector<float> j_ext;     // (J,3,S+1)  [J_template | J_shapedirs]
+  std::vector<float> bone_ext;  // (J,3,S+1)  j_ext - j_ext[parent] (root: j_ext - j_ext[0] = 0)
+  std::vector<float> sa0;       // (J,3) sum of default-mesh vertices per part (template pass)
+  std::vector<float> sw0;       // (J)   vertex count per part
+
+  // sparse post-LBS joint regressor, CSR over sorted slots (joints-omitted path)
+  std::vector<int32_t> reg_start, reg_slot;
+  std::vector<float> reg_val;
+
+  int num_levels() const { return (int)fk_level_start.size() - 1; }
+  int ne() const { return S * (S + 1) / 2 + S + 3 * S + 3; }  // normal-equation entries (+1 for W)
+};
+
+// Returns "" on success, else an error message (and `unsupported` tells which status to use).
+std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsupported);
+
+}  // namespace sf

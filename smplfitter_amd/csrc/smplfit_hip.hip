@@ -1,0 +1,1079 @@
+// libsmplfit_hip.so — HIP kernels (gfx950 / CDNA4) and the C-ABI of include/smplfit.h.
+//
+// Kernel inventory (one launch each; grid = instances unless noted):
+//   k_center_sort_partsum  K0  mean-centre targets, re-order vertices by body part (SoA), part sums
+//                              against the template mesh           [HBM-bound streaming + wave sums]
+//   k_joint_stage          K1  part rotations (SO(3) projections, swing-twist), shape prologue
+//                              (FK + beta-Jacobian, pose feature, joint normal equations)  [1 wave]
+//   k_posedirs_gemm        K2  v_posed = v_template + pose_feature . posedirs, fp32 MFMA 32x32x2,
+//                              128x128 LDS-tiled, grid = tiles                           [MFMA-bound]
+//   k_shape_accum          K3  per-vertex blended rotation / position / shape Jacobian from LDS
+//                              joint block, 98 normal-equation sums per instance         [VALU-bound]
+//   k_shape_solve          K4  fp64 centring + 10x10 Cholesky + translation                 [1 wave]
+//   k_lbs_partsum          K5  vertices at the solved shape (LBS) fused with the part sums of the
+//                              next rotation pass — the re-evaluated mesh never reaches HBM
+//   k_refine_epilogue      K6  dependent rotation refinement + relative rotations + log map [1 wave]
+//   k_forward_joint / k_lbs_forward   BodyModel.forward
+// Everything is enqueued on the caller's stream; no host synchronisation, no allocation.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/smplfit.h"
+#include "sf_stages.h"
+#include "sf_tables.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define SF_HIP_TRY(expr)                                                                   \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fail(SMPLFIT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// device-side model
+// ------------------------------------------------------------------------------------------------
+struct DevModel {
+  int V, J, S, P, Vp, Kp, KW, n_used, nseg;
+  sf::JointTabs jt;
+  const int32_t* perm;      // (Vp)
+  const int32_t* segments;  // (nseg,3)
+  const float *vt, *dm, *sd, *wval, *pdT, *vtN, *j_template;
+  const uint32_t* widx;
+  const int32_t *reg_start, *reg_slot;
+  const float* reg_val;
+};
+
+}  // namespace
+
+struct smplfit_handle {
+  sf::HostTables t;
+  DevModel d{};
+  std::vector<void*> allocs;
+  bool has_device = false;
+};
+
+namespace {
+
+struct DevCtx {
+  int lane, n;
+  __device__ __forceinline__ void sync() const { __syncthreads(); }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Per-call workspace carve (device pointers).
+struct Workspace {
+  float* tvs;      // (B,3,Vp)   centred targets, sorted slots, SoA
+  float* vws;      // (B,Vp)     vertex weights, sorted slots (when given)
+  float* vposed;   // (Mp,3*Vp)  GEMM output
+  float* rp;       // (Mp,Kp)    pose features (GEMM A)
+  float* mean;     // (B,3)
+  float* tjc;      // (B,J,3)    centred target joints
+  float* psum;     // (B,J,16)
+  float* G;        // (B,J,9)
+  float* jd;       // (B,J,jd_stride)
+  float* pext;     // (B,J,3,S+1)
+  float* gramj;    // (B,NE+1)
+  double* gramv;   // (B,NE+1)
+  float* beta;     // (B,S)
+  float* trans;    // (B,3)
+  float* jb;       // (B,J,4)
+  float* rjoints;  // (B,J,3)
+  float* rverts;   // (B,3,Vp) re-evaluated vertices (joints-omitted path only)
+  float* tjreg;    // (B,J,3) regressed target joints (joints-omitted path)
+  float* rjreg;    // (B,J,3) regressed reference joints
+};
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w) {
+  const size_t Mp = align_up((size_t)B, 128);
+  const size_t Vp = t.Vp, J = t.J, S = t.S, NE1 = t.ne() + 1;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off = align_up(off + bytes, 256);
+    return base ? base + o : nullptr;
+  };
+  Workspace ws;
+  ws.tvs = (float*)take((size_t)B * 3 * Vp * 4);
+  ws.vws = (float*)take((size_t)B * Vp * 4);
+  ws.vposed = (float*)take(Mp * 3 * Vp * 4);
+  ws.rp = (float*)take(Mp * t.Kp * 4);
+  ws.mean = (float*)take((size_t)B * 3 * 4);
+  ws.tjc = (float*)take((size_t)B * J * 3 * 4);
+  ws.psum = (float*)take((size_t)B * J * sf::kPsum * 4);
+  ws.G = (float*)take((size_t)B * J * 9 * 4);
+  ws.jd = (float*)take((size_t)B * J * sf::jd_stride(S) * 4);
+  ws.pext = (float*)take((size_t)B * J * 3 * (S + 1) * 4);
+  ws.gramj = (float*)take((size_t)B * NE1 * 4);
+  ws.gramv = (double*)take((size_t)B * NE1 * 8);
+  ws.beta = (float*)take((size_t)B * S * 4);
+  ws.trans = (float*)take((size_t)B * 3 * 4);
+  ws.jb = (float*)take((size_t)B * J * 4 * 4);
+  ws.rjoints = (float*)take((size_t)B * J * 3 * 4);
+  ws.rverts = (float*)take((size_t)B * 3 * Vp * 4);
+  ws.tjreg = (float*)take((size_t)B * J * 3 * 4);
+  ws.rjreg = (float*)take((size_t)B * J * 3 * 4);
+  if (w) *w = ws;
+  return off;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0: centre + sort + template part sums.  grid B, block 256.
+// reference: fit() centring bodyfitter.py:355-361; _part_sums :235-280 against default_mesh_tf.
+// dynamic LDS: 4 waves x J x 16 floats + 20 (no static LDS: keeps the dynamic base 16-B aligned).
+// ------------------------------------------------------------------------------------------------
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void k_center_sort_partsum(DevModel m, const float* __restrict__ tv,
+                                                             const float* __restrict__ tj,
+                                                             const float* __restrict__ vw,
+                                                             Workspace ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int V = m.V, J = m.J, Vp = m.Vp;
+  float(*red)[4] = reinterpret_cast<float(*)[4]>(smem + 4 * J * sf::kPsum);  // [4][4]
+  float* mu = smem + 4 * J * sf::kPsum + 16;                                // [4]
+  const float* tvb = tv + (size_t)b * V * 3;
+  // ---- mean over the V (+J) points
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int v = tid; v < V; v += 256) {
+    sx += tvb[v * 3];
+    sy += tvb[v * 3 + 1];
+    sz += tvb[v * 3 + 2];
+  }
+  if (tj) {
+    for (int j = tid; j < J; j += 256) {
+      sx += tj[((size_t)b * J + j) * 3];
+      sy += tj[((size_t)b * J + j) * 3 + 1];
+      sz += tj[((size_t)b * J + j) * 3 + 2];
+    }
+  }
+  sx = wave_sum(sx);
+  sy = wave_sum(sy);
+  sz = wave_sum(sz);
+  if (lane == 0) {
+    red[wave][0] = sx;
+    red[wave][1] = sy;
+    red[wave][2] = sz;
+  }
+  for (int k = tid; k < 4 * J * sf::kPsum; k += 256) smem[k] = 0.f;
+  __syncthreads();
+  if (tid < 3) {
+    const float n = (float)(V + (tj ? J : 0));
+    const float s = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    mu[tid] = s / n;
+    ws.mean[b * 3 + tid] = s / n;
+  }
+  __syncthreads();
+  const float m0 = mu[0], m1 = mu[1], m2 = mu[2];
+  if (tj)
+    for (int k = tid; k < J * 3; k += 256)
+      ws.tjc[(size_t)b * J * 3 + k] = tj[(size_t)b * J * 3 + k] - mu[k % 3];
+  // ---- used parts: gather, centre, store sorted SoA, accumulate part sums per segment
+  float* tvs = ws.tvs + (size_t)b * 3 * Vp;
+  float* vws = ws.vws + (size_t)b * Vp;
+  const int s_begin = (int)((long)m.nseg * wave / 4), s_end = (int)((long)m.nseg * (wave + 1) / 4);
+  float acc[sf::kPsum];
+#pragma unroll
+  for (int k = 0; k < sf::kPsum; ++k) acc[k] = 0.f;
+  for (int s = s_begin; s < s_end; ++s) {
+    const int start = m.segments[s * 3], count = m.segments[s * 3 + 1], part = m.segments[s * 3 + 2];
+    if (lane < count) {
+      const int i = start + lane, o = m.perm[i];
+      const float t[3] = {tvb[o * 3] - m0, tvb[o * 3 + 1] - m1, tvb[o * 3 + 2] - m2};
+      tvs[i] = t[0];
+      tvs[Vp + i] = t[1];
+      tvs[2 * Vp + i] = t[2];
+      const float a[3] = {m.dm[i], m.dm[Vp + i], m.dm[2 * Vp + i]};
+      float w = 1.f;
+      if (WEIGHTED) {
+        w = vw[(size_t)b * V + o];
+        vws[i] = w;
+      }
+      sf::partsum_vertex(t, a, w, WEIGHTED, acc);
+    }
+    const bool flush = (s + 1 == s_end) || (m.segments[(s + 1) * 3 + 2] != part);
+    if (flush) {
+#pragma unroll
+      for (int k = 0; k < sf::kPsum; ++k) {
+        const float r = wave_sum(acc[k]);
+        if (lane == 0) smem[(wave * J + part) * sf::kPsum + k] = r;
+        acc[k] = 0.f;
+      }
+    }
+  }
+  // ---- the remaining (unused-part and padding) slots: store only
+  for (int i = m.n_used + tid; i < Vp; i += 256) {
+    const int o = m.perm[i];
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, w = 0.f;
+    if (o >= 0) {
+      t0 = tvb[o * 3] - m0;
+      t1 = tvb[o * 3 + 1] - m1;
+      t2 = tvb[o * 3 + 2] - m2;
+      if (WEIGHTED) w = vw[(size_t)b * V + o];
+    }
+    tvs[i] = t0;
+    tvs[Vp + i] = t1;
+    tvs[2 * Vp + i] = t2;
+    if (WEIGHTED) vws[i] = w;
+  }
+  __syncthreads();
+  for (int k = tid; k < J * sf::kPsum; k += 256)
+    ws.psum[(size_t)b * J * sf::kPsum + k] =
+        (smem[k] + smem[J * sf::kPsum + k]) + (smem[2 * J * sf::kPsum + k] + smem[3 * J * sf::kPsum + k]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// sparse post-LBS joint regression (joints-omitted path): out[b][j] = sum_k reg_val * src[b][:, slot]
+// reference: bodyfitter.py:1342-1344.  grid B, block 64.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_regress_joints(DevModel m, const float* __restrict__ src,
+                                                       float* __restrict__ out) {
+  const int b = blockIdx.x;
+  const float* s = src + (size_t)b * 3 * m.Vp;
+  for (int j = threadIdx.x; j < m.J; j += 64) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int k = m.reg_start[j]; k < m.reg_start[j + 1]; ++k) {
+      const int i = m.reg_slot[k];
+      const float r = m.reg_val[k];
+      a0 += r * s[i];
+      a1 += r * s[m.Vp + i];
+      a2 += r * s[2 * m.Vp + i];
+    }
+    out[((size_t)b * m.J + j) * 3] = a0;
+    out[((size_t)b * m.J + j) * 3 + 1] = a1;
+    out[((size_t)b * m.J + j) * 3 + 2] = a2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: joint stage.  grid B, block 64.  dynamic LDS = joint_scratch_floats.
+// ------------------------------------------------------------------------------------------------
+struct JointStageArgs {
+  const float* tj;       // (B,J,3) centred target joints (given or regressed)
+  const float* rj;       // (B,J,3) reference joints, or (J,3) template when rj_shared
+  int rj_shared;
+  const float* Gprev;    // (B,J,9) or null
+  const float* jw;       // (B,J) or null
+  int fit_rotations, do_prologue, joint_block, joint_block_weighted;
+};
+
+__global__ __launch_bounds__(64) void k_joint_stage(DevModel m, JointStageArgs a, Workspace ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, J = m.J, S = m.S;
+  DevCtx cx{(int)threadIdx.x, 64};
+  sf::JointScratch sh = sf::carve_joint_scratch(smem, J, S);
+  const int NE1 = sf::ne_size(S) + 1;
+  sf::joint_stage(cx, m.jt, sh, ws.psum + (size_t)b * J * sf::kPsum, a.tj + (size_t)b * J * 3,
+                  a.rj_shared ? a.rj : a.rj + (size_t)b * J * 3,
+                  a.Gprev ? a.Gprev + (size_t)b * J * 9 : nullptr,
+                  a.jw ? a.jw + (size_t)b * J : nullptr, a.fit_rotations != 0, a.do_prologue != 0,
+                  a.joint_block != 0,
+                  a.joint_block_weighted != 0, ws.G + (size_t)b * J * 9,
+                  ws.rp + (size_t)b * m.Kp, ws.jd + (size_t)b * J * sf::jd_stride(S),
+                  ws.pext + (size_t)b * J * 3 * (S + 1), ws.gramj + (size_t)b * NE1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: v_posed[Mp][N] = bias[N] + A[Mp][Kp] . Bm[Kp][N]   (fp32 MFMA 32x32x2, exact f32)
+// reference: bodyfitter.py:913-916 einsum('vcp,bp->bvc').  N = 3*Vp, column n = c*Vp + slot.
+// 128x128 block tile, 4 waves x (64x64), K step 16, register-prefetched double-buffered LDS.
+// grid = (N/128) * (Mp/128), n-tile major so the blocks of one posedirs column tile run together.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void k_posedirs_gemm(const float* __restrict__ A,
+                                                       const float* __restrict__ Bm,
+                                                       const float* __restrict__ bias,
+                                                       float* __restrict__ C, int Mp, int N, int Kp) {
+  __shared__ float As[2][128][17];
+  __shared__ __attribute__((aligned(16))) float Bs[2][16][128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mtiles = Mp / 128;
+  const int ntile = blockIdx.x / mtiles, mtile = blockIdx.x % mtiles;
+  const int m0 = mtile * 128, n0 = ntile * 128;
+  const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+  const int l31 = lane & 31, lk = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const float bv = bias[n0 + wn + ni * 32 + l31];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = bv;
+  }
+  // global -> register staging: A 128x16 (2 float4 / thread), B 16x128 (2 float4 / thread)
+  const int a_row = tid >> 2, a_kc = (tid & 3) * 4;
+  const int b_row = tid >> 5, b_nc = (tid & 31) * 4;
+  float4 ra[2], rb[2];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      ra[h] = *reinterpret_cast<const float4*>(A + (size_t)(m0 + a_row + 64 * h) * Kp + k0 + a_kc);
+      rb[h] = *reinterpret_cast<const float4*>(Bm + (size_t)(k0 + b_row + 8 * h) * N + n0 + b_nc);
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float* ap = &As[buf][a_row + 64 * h][a_kc];
+      ap[0] = ra[h].x; ap[1] = ra[h].y; ap[2] = ra[h].z; ap[3] = ra[h].w;
+      *reinterpret_cast<float4*>(&Bs[buf][b_row + 8 * h][b_nc]) = rb[h];
+    }
+  };
+  const int nk = Kp / 16;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int it = 0; it < nk; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < nk) gload((it + 1) * 16);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const float a0 = As[buf][wm + l31][2 * kk + lk];
+      const float a1 = As[buf][wm + 32 + l31][2 * kk + lk];
+      const float b0 = Bs[buf][2 * kk + lk][wn + l31];
+      const float b1 = Bs[buf][2 * kk + lk][wn + 32 + l31];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (it + 1 < nk) sstore(buf ^ 1);
+    __syncthreads();
+  }
+  // C layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int col = n0 + wn + ni * 32 + l31;
+        C[(size_t)row * N + col] = acc[mi][ni][r];
+      }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: vertex block of the normal equations.  grid B, block 256.
+// dynamic LDS: joint block (J*jd_stride floats) + 4 x (NE+1) wave partials.
+// ------------------------------------------------------------------------------------------------
+template <int S, int KW, bool WEIGHTED>
+__global__ __launch_bounds__(256) void k_shape_accum(DevModel m, Workspace ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NE = sf::ne_size(S), STRIDE = sf::jd_stride(S);
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int J = m.J, Vp = m.Vp;
+  float* jd = smem;
+  float* red = smem + J * STRIDE;  // [4][NE+1]
+  {
+    const float4* src = reinterpret_cast<const float4*>(ws.jd + (size_t)b * J * STRIDE);
+    float4* dst = reinterpret_cast<float4*>(jd);
+    for (int k = tid; k < J * STRIDE / 4; k += 256) dst[k] = src[k];
+  }
+  __syncthreads();
+  const float* tvs = ws.tvs + (size_t)b * 3 * Vp;
+  const float* vps = ws.vposed + (size_t)b * 3 * Vp;
+  const float* vws = ws.vws + (size_t)b * Vp;
+  float acc[NE + 1];
+#pragma unroll
+  for (int k = 0; k <= NE; ++k) acc[k] = 0.f;
+  for (int tile = wave; tile < Vp / 64; tile += 4) {
+    const int i = tile * 64 + lane;
+    const sf::Skin<KW> sk = sf::load_skin<KW>(m.widx, m.wval, Vp, i);
+    const float vp[3] = {vps[i], vps[Vp + i], vps[2 * Vp + i]};
+    const float tv[3] = {tvs[i], tvs[Vp + i], tvs[2 * Vp + i]};
+    float sdv[3 * S];
+#pragma unroll
+    for (int k = 0; k < 3 * S; ++k) sdv[k] = m.sd[(size_t)k * Vp + i];
+    float wv = 1.f;
+    if (WEIGHTED) {
+      wv = vws[i];
+      acc[NE] += wv;
+    }
+    sf::shape_accum_vertex<S, KW, WEIGHTED>(jd, sk, vp, tv, sdv, wv, acc);
+  }
+#pragma unroll
+  for (int k = 0; k <= NE; ++k) {
+    const float r = wave_sum(acc[k]);
+    if (lane == 0) red[wave * (NE + 1) + k] = r;
+  }
+  __syncthreads();
+  for (int k = tid; k <= NE; k += 256) {
+    double v = ((double)red[k] + (double)red[(NE + 1) + k]) +
+               ((double)red[2 * (NE + 1) + k] + (double)red[3 * (NE + 1) + k]);
+    if (!WEIGHTED && k == NE) v = (double)m.V;  // w_sum = num_vertices (bodyfitter.py:1038-1040)
+    ws.gramv[(size_t)b * (NE + 1) + k] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: solve.  grid B, block 64.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_shape_solve(DevModel m, Workspace ws, float beta_reg,
+                                                    float beta_reg2) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, J = m.J, S = m.S;
+  DevCtx cx{(int)threadIdx.x, 64};
+  sf::JointScratch sh = sf::carve_joint_scratch(smem, J, S);
+  const int NE1 = sf::ne_size(S) + 1;
+  sf::solve_stage(cx, m.jt, sh, ws.gramv + (size_t)b * NE1, ws.gramj + (size_t)b * NE1,
+                  ws.pext + (size_t)b * J * 3 * (S + 1), ws.jd + (size_t)b * J * sf::jd_stride(S),
+                  beta_reg, beta_reg2, ws.beta + (size_t)b * S, ws.trans + (size_t)b * 3,
+                  ws.rjoints + (size_t)b * J * 3, ws.jb + (size_t)b * J * 4);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: vertices at the solved shape + part sums against the targets.  grid B, block 256.
+// MODE 0: part sums only (joints given).  MODE 1: also store the vertices (sorted SoA) for the
+// joint regression of the joints-omitted path.  MODE 2: store vertices in ORIGINAL order to `out`
+// (B,V,3) (shape-solve entry point / forward) — no part sums.
+// dynamic LDS: joint block + jb (J*4) + 4 x J x 16 partials.
+// ------------------------------------------------------------------------------------------------
+template <int S, int KW, bool WEIGHTED, int MODE>
+__global__ __launch_bounds__(256) void k_lbs_partsum(DevModel m, Workspace ws, int nb,
+                                                     const float* __restrict__ beta_in,
+                                                     const float* __restrict__ trans_in,
+                                                     float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int STRIDE = sf::jd_stride(S);
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int J = m.J, Vp = m.Vp, V = m.V;
+  float* jd = smem;
+  float* jb = jd + J * STRIDE;
+  float* pacc = jb + J * 4;
+  float* sbeta = pacc + 4 * J * sf::kPsum;  // [32]
+  float* strans = sbeta + 32;               // [4]
+  {
+    const float4* src = reinterpret_cast<const float4*>(ws.jd + (size_t)b * J * STRIDE);
+    float4* dst = reinterpret_cast<float4*>(jd);
+    for (int k = tid; k < J * STRIDE / 4; k += 256) dst[k] = src[k];
+    for (int k = tid; k < J * 4; k += 256) jb[k] = ws.jb[(size_t)b * J * 4 + k];
+    if (MODE != 2)
+      for (int k = tid; k < 4 * J * sf::kPsum; k += 256) pacc[k] = 0.f;
+    if (tid < S) sbeta[tid] = (beta_in && tid < nb) ? beta_in[(size_t)b * nb + tid] : 0.f;
+    if (tid < 3) strans[tid] = trans_in ? trans_in[(size_t)b * 3 + tid] : 0.f;
+  }
+  __syncthreads();
+  const float* tvs = ws.tvs + (size_t)b * 3 * Vp;
+  const float* vps = ws.vposed + (size_t)b * 3 * Vp;
+  const float* vws = ws.vws + (size_t)b * Vp;
+  float beta[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) beta[s] = sbeta[s];
+  const float trans[3] = {strans[0], strans[1], strans[2]};
+
+  auto vertex = [&](int i, float* v) {
+    const sf::Skin<KW> sk = sf::load_skin<KW>(m.widx, m.wval, Vp, i);
+    const float vp[3] = {vps[i], vps[Vp + i], vps[2 * Vp + i]};
+    float sdv[3 * S];
+#pragma unroll
+    for (int k = 0; k < 3 * S; ++k) sdv[k] = m.sd[(size_t)k * Vp + i];
+    sf::lbs_vertex<S, KW>(jd, jb, sk, vp, sdv, beta, S, trans, v);
+  };
+
+  if (MODE == 2) {
+    for (int i = tid; i < Vp; i += 256) {
+      const int o = m.perm[i];
+      if (o >= 0) {
+        float v[3];
+        vertex(i, v);
+        out[((size_t)b * V + o) * 3] = v[0];
+        out[((size_t)b * V + o) * 3 + 1] = v[1];
+        out[((size_t)b * V + o) * 3 + 2] = v[2];
+      }
+    }
+    return;
+  }
+  float* rv = ws.rverts + (size_t)b * 3 * Vp;
+  const int s_begin = (int)((long)m.nseg * wave / 4), s_end = (int)((long)m.nseg * (wave + 1) / 4);
+  float acc[sf::kPsum];
+#pragma unroll
+  for (int k = 0; k < sf::kPsum; ++k) acc[k] = 0.f;
+  for (int s = s_begin; s < s_end; ++s) {
+    const int start = m.segments[s * 3], count = m.segments[s * 3 + 1], part = m.segments[s * 3 + 2];
+    if (lane < count) {
+      const int i = start + lane;
+      float v[3];
+      vertex(i, v);
+      if (MODE == 1) {
+        rv[i] = v[0];
+        rv[Vp + i] = v[1];
+        rv[2 * Vp + i] = v[2];
+      }
+      const float t[3] = {tvs[i], tvs[Vp + i], tvs[2 * Vp + i]};
+      sf::partsum_vertex(t, v, WEIGHTED ? vws[i] : 1.f, WEIGHTED, acc);
+    }
+    const bool flush = (s + 1 == s_end) || (m.segments[(s + 1) * 3 + 2] != part);
+    if (flush) {
+#pragma unroll
+      for (int k = 0; k < sf::kPsum; ++k) {
+        const float r = wave_sum(acc[k]);
+        if (lane == 0) pacc[(wave * J + part) * sf::kPsum + k] = r;
+        acc[k] = 0.f;
+      }
+    }
+  }
+  if (MODE == 1) {
+    for (int i = m.n_used + tid; i < Vp; i += 256) {
+      float v[3] = {0.f, 0.f, 0.f};
+      if (m.perm[i] >= 0) vertex(i, v);
+      rv[i] = v[0];
+      rv[Vp + i] = v[1];
+      rv[2 * Vp + i] = v[2];
+    }
+  }
+  __syncthreads();
+  for (int k = tid; k < J * sf::kPsum; k += 256)
+    ws.psum[(size_t)b * J * sf::kPsum + k] =
+        (pacc[k] + pacc[J * sf::kPsum + k]) + (pacc[2 * J * sf::kPsum + k] + pacc[3 * J * sf::kPsum + k]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6: dependent refinement + epilogue.  grid B, block 64.
+// ------------------------------------------------------------------------------------------------
+struct RefineArgs {
+  const float* tj;        // (B,J,3) joints of the joint term (centred targets or regressed)
+  const float* rj_term;   // (B,J,3) reference joints of the joint term
+  const float* jw;        // (B,J) or null
+  int final_adjust;
+  float *pose, *betas, *trans, *orient;
+};
+
+__global__ __launch_bounds__(64) void k_refine_epilogue(DevModel m, RefineArgs a, Workspace ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, J = m.J, S = m.S;
+  DevCtx cx{(int)threadIdx.x, 64};
+  sf::JointScratch sh = sf::carve_joint_scratch(smem, J, S);
+  sf::refine_stage(cx, m.jt, sh, ws.psum + (size_t)b * J * sf::kPsum, a.tj + (size_t)b * J * 3,
+                   a.rj_term + (size_t)b * J * 3, ws.rjoints + (size_t)b * J * 3,
+                   a.jw ? a.jw + (size_t)b * J : nullptr, ws.G + (size_t)b * J * 9,
+                   ws.beta + (size_t)b * S, ws.trans + (size_t)b * 3, ws.mean + (size_t)b * 3,
+                   a.final_adjust != 0, a.pose + (size_t)b * J * 3, a.betas + (size_t)b * S,
+                   a.trans + (size_t)b * 3, a.orient ? a.orient + (size_t)b * J * 9 : nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: joint prologue.  grid B, block 64.
+// ------------------------------------------------------------------------------------------------
+struct ForwardArgs {
+  const float *pose, *glob, *betas, *trans;
+  int nb;
+  float *joints, *orient;
+};
+
+__global__ __launch_bounds__(64) void k_forward_joint(DevModel m, ForwardArgs a, Workspace ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, J = m.J, S = m.S;
+  DevCtx cx{(int)threadIdx.x, 64};
+  sf::JointScratch sh = sf::carve_joint_scratch(smem, J, S);
+  float* jd = ws.jd + (size_t)b * J * sf::jd_stride(S);
+  sf::forward_joint_stage(cx, m.jt, sh, a.pose ? a.pose + (size_t)b * J * 3 : nullptr,
+                          a.glob ? a.glob + (size_t)b * J * 9 : nullptr,
+                          a.betas ? a.betas + (size_t)b * a.nb : nullptr, a.betas ? a.nb : 0,
+                          a.trans ? a.trans + (size_t)b * 3 : nullptr, ws.rp + (size_t)b * m.Kp, jd,
+                          a.joints + (size_t)b * J * 3,
+                          a.orient ? a.orient + (size_t)b * J * 9 : nullptr);
+  __syncthreads();
+  // skinning translations for the vertex kernel
+  for (int k = threadIdx.x; k < J * 3; k += 64)
+    ws.jb[(size_t)b * J * 4 + (k / 3) * 4 + k % 3] = jd[(k / 3) * sf::jd_stride(S) + 9 + k % 3];
+}
+
+// scatter G given by the caller into the workspace (shape-solve entry point)
+__global__ void k_copy(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+template <int S, int KW>
+int launch_shape_accum(const DevModel& d, const Workspace& ws, int B, bool weighted, hipStream_t st) {
+  const size_t lds = ((size_t)d.J * sf::jd_stride(S) + 4 * (sf::ne_size(S) + 1)) * 4;
+  if (weighted)
+    hipLaunchKernelGGL((k_shape_accum<S, KW, true>), dim3(B), dim3(256), lds, st, d, ws);
+  else
+    hipLaunchKernelGGL((k_shape_accum<S, KW, false>), dim3(B), dim3(256), lds, st, d, ws);
+  return 0;
+}
+
+template <int S, int KW, int MODE>
+void launch_lbs(const DevModel& d, const Workspace& ws, int B, bool weighted, int nb,
+                const float* beta, const float* trans, float* out, hipStream_t st) {
+  const size_t lds = ((size_t)d.J * sf::jd_stride(S) + d.J * 4 + 4 * d.J * sf::kPsum + 36) * 4;
+  if (weighted)
+    hipLaunchKernelGGL((k_lbs_partsum<S, KW, true, MODE>), dim3(B), dim3(256), lds, st, d, ws, nb,
+                       beta, trans, out);
+  else
+    hipLaunchKernelGGL((k_lbs_partsum<S, KW, false, MODE>), dim3(B), dim3(256), lds, st, d, ws, nb,
+                       beta, trans, out);
+}
+
+#define SF_DISPATCH_SKW(d, CALL)                                               \
+  do {                                                                         \
+    if ((d).S == 10 && (d).KW == 4) { CALL(10, 4); }                           \
+    else if ((d).S == 10 && (d).KW == 8) { CALL(10, 8); }                      \
+    else if ((d).S == 16 && (d).KW == 4) { CALL(16, 4); }                      \
+    else if ((d).S == 16 && (d).KW == 8) { CALL(16, 8); }                      \
+    else return fail(SMPLFIT_ERR_UNSUPPORTED,                                  \
+                     "num_betas must be 10 or 16 for the HIP kernels");        \
+  } while (0)
+
+int check_common(const smplfit_handle* h, int batch, void* workspace, size_t workspace_bytes) {
+  if (!h) return fail(SMPLFIT_ERR_BAD_ARG, "null handle");
+  if (!h->has_device) return fail(SMPLFIT_ERR_HIP, "handle was created host-only (no device)");
+  if (batch <= 0) return fail(SMPLFIT_ERR_BAD_ARG, "batch must be positive");
+  if (!workspace || ((uintptr_t)workspace & 255))
+    return fail(SMPLFIT_ERR_WORKSPACE, "workspace must be a 256-byte aligned device pointer");
+  if (workspace_bytes < carve(h->t, batch, nullptr, nullptr))
+    return fail(SMPLFIT_ERR_WORKSPACE, "workspace too small (see smplfit_workspace_bytes)");
+  return 0;
+}
+
+int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st) {
+  const int Mp = (int)align_up((size_t)B, 128), N = 3 * d.Vp;
+  hipLaunchKernelGGL(k_posedirs_gemm, dim3((N / 128) * (Mp / 128)), dim3(256), 0, st, ws.rp, d.pdT,
+                     d.vtN, ws.vposed, Mp, N, d.Kp);
+  return 0;
+}
+
+size_t joint_lds(const DevModel& d) { return (size_t)sf::joint_scratch_floats(d.J, d.S) * 4; }
+
+int post_launch_check() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(SMPLFIT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+  return 0;
+}
+
+// Shared driver of fit / part_rotations / shape_solve.
+struct FitOptions {
+  int num_iter;
+  float beta_reg, beta_reg2;
+  int final_adjust;
+  int rotations_only;  // stop after the first rotation pass, write G to `orient`
+};
+
+int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const float* vw,
+            const float* jw, int B, const FitOptions& o, float* pose, float* betas, float* trans,
+            float* orient, const Workspace& ws, hipStream_t st) {
+  const DevModel& d = h->d;
+  const bool joints = tj != nullptr;
+  if (!joints && !h->t.has_regressor)
+    return fail(SMPLFIT_ERR_BAD_ARG,
+                "target_joints omitted but the model has no J_regressor_post_lbs over its vertices");
+  const bool vweighted = vw != nullptr;
+  // weights enter the shape solve only if both are given (with joints) or vertex weights without
+  // joints (bodyfitter.py:1018-1028)
+  const bool eff_v = joints ? (vw && jw) : (vw != nullptr);
+  const bool eff_j = joints && vw && jw;
+  const size_t lds0 = ((size_t)4 * d.J * sf::kPsum + 20) * 4;
+  if (vweighted)
+    hipLaunchKernelGGL((k_center_sort_partsum<true>), dim3(B), dim3(256), lds0, st, d, tv, tj, vw, ws);
+  else
+    hipLaunchKernelGGL((k_center_sort_partsum<false>), dim3(B), dim3(256), lds0, st, d, tv, tj, vw, ws);
+  const float* tj_rot = ws.tjc;
+  if (!joints) {  // regressed target joints from the centred vertices (bodyfitter.py:1342-1344)
+    hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(64), 0, st, d, ws.tvs, ws.tjreg);
+    tj_rot = ws.tjreg;
+  }
+  JointStageArgs ja{};
+  ja.tj = tj_rot;
+  ja.jw = jw;
+  ja.joint_block = joints ? 1 : 0;
+  ja.joint_block_weighted = eff_j ? 1 : 0;
+  ja.do_prologue = o.rotations_only ? 0 : 1;
+  ja.fit_rotations = 1;
+  if (joints) {
+    ja.rj = d.j_template;
+    ja.rj_shared = 1;
+  } else {  // template joints regressed from the default mesh: same regressor on a (1,3,Vp) source
+    hipLaunchKernelGGL(k_regress_joints, dim3(1), dim3(64), 0, st, d, d.dm, ws.rjreg);
+    ja.rj = ws.rjreg;
+    ja.rj_shared = 1;
+  }
+  ja.Gprev = nullptr;
+  hipLaunchKernelGGL(k_joint_stage, dim3(B), dim3(64), joint_lds(d), st, d, ja, ws);
+  if (o.rotations_only) {
+    hipLaunchKernelGGL(k_copy, dim3(256), dim3(256), 0, st, ws.G, orient, (size_t)B * d.J * 9);
+    return post_launch_check();
+  }
+  for (int it = 0; it < o.num_iter; ++it) {
+    launch_gemm(d, ws, B, st);
+#define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, B, eff_v, st)
+    SF_DISPATCH_SKW(d, SF_CALL_ACCUM);
+#undef SF_CALL_ACCUM
+    hipLaunchKernelGGL(k_shape_solve, dim3(B), dim3(64), joint_lds(d), st, d, ws, o.beta_reg,
+                       o.beta_reg2);
+    const bool last = it + 1 == o.num_iter;
+    if (last && !o.final_adjust) break;
+    if (joints) {
+#define SF_CALL_LBS(S_, KW_) launch_lbs<S_, KW_, 0>(d, ws, B, vweighted, d.S, ws.beta, ws.trans, nullptr, st)
+      SF_DISPATCH_SKW(d, SF_CALL_LBS);
+#undef SF_CALL_LBS
+    } else {
+#define SF_CALL_LBS(S_, KW_) launch_lbs<S_, KW_, 1>(d, ws, B, vweighted, d.S, ws.beta, ws.trans, nullptr, st)
+      SF_DISPATCH_SKW(d, SF_CALL_LBS);
+#undef SF_CALL_LBS
+      hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(64), 0, st, d, ws.rverts, ws.rjreg);
+    }
+    if (last) break;
+    ja.rj = joints ? ws.rjoints : ws.rjreg;
+    ja.rj_shared = 0;
+    ja.Gprev = ws.G;
+    hipLaunchKernelGGL(k_joint_stage, dim3(B), dim3(64), joint_lds(d), st, d, ja, ws);
+  }
+  RefineArgs ra{};
+  ra.tj = tj_rot;
+  ra.rj_term = joints ? ws.rjoints : ws.rjreg;
+  ra.jw = jw;
+  ra.final_adjust = o.final_adjust;
+  ra.pose = pose;
+  ra.betas = betas;
+  ra.trans = trans;
+  ra.orient = orient;
+  hipLaunchKernelGGL(k_refine_epilogue, dim3(B), dim3(64), joint_lds(d), st, d, ra, ws);
+  return post_launch_check();
+}
+
+template <typename T>
+int upload(smplfit_handle* h, const std::vector<T>& src, const T** dst) {
+  void* p = nullptr;
+  const size_t bytes = std::max<size_t>(src.size() * sizeof(T), 16);
+  SF_HIP_TRY(hipMalloc(&p, bytes));
+  h->allocs.push_back(p);
+  if (!src.empty()) SF_HIP_TRY(hipMemcpy(p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  *dst = (const T*)p;
+  return 0;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C-ABI
+// ================================================================================================
+extern "C" {
+
+const char* smplfit_last_error(void) { return g_last_error.c_str(); }
+const char* smplfit_version(void) { return "smplfit-hip 0.1 (gfx950)"; }
+
+int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** out) {
+  if (!desc || !out) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_create: null argument");
+  *out = nullptr;
+  smplfit_handle* h = new smplfit_handle();
+  bool unsupported = false;
+  std::string err = sf::build_tables(*desc, h->t, &unsupported);
+  if (!err.empty()) {
+    delete h;
+    return fail(unsupported ? SMPLFIT_ERR_UNSUPPORTED : SMPLFIT_ERR_BAD_ARG, err);
+  }
+  if (h->t.S + 3 > 3 * h->t.J) {
+    delete h;
+    return fail(SMPLFIT_ERR_UNSUPPORTED, "smplfit_create: num_betas too large for this joint count");
+  }
+  if (flags & SMPLFIT_CREATE_HOST_ONLY) {
+    *out = h;
+    return SMPLFIT_OK;
+  }
+  const sf::HostTables& t = h->t;
+  DevModel& d = h->d;
+  d.V = t.V; d.J = t.J; d.S = t.S; d.P = t.P; d.Vp = t.Vp; d.Kp = t.Kp; d.KW = t.KW;
+  d.n_used = t.n_used;
+  d.nseg = (int)t.segments.size();
+  std::vector<int32_t> seg;
+  for (auto& s : t.segments) {
+    seg.push_back(s.start);
+    seg.push_back(s.count);
+    seg.push_back(s.part);
+  }
+  std::vector<float> jtemplate((size_t)t.J * 3);
+  for (int k = 0; k < t.J * 3; ++k) jtemplate[k] = t.j_ext[(size_t)k * (t.S + 1)];
+  int rc = 0;
+  auto up = [&](auto& vec, auto** dst) {
+    if (rc == 0) rc = upload(h, vec, dst);
+  };
+  up(t.perm, &d.perm);
+  up(seg, &d.segments);
+  up(t.vt, &d.vt);
+  up(t.dm, &d.dm);
+  up(t.sd, &d.sd);
+  up(t.wval, &d.wval);
+  up(t.widx, &d.widx);
+  up(t.pdT, &d.pdT);
+  up(t.vtN, &d.vtN);
+  up(jtemplate, &d.j_template);
+  up(t.reg_start, &d.reg_start);
+  up(t.reg_slot, &d.reg_slot);
+  up(t.reg_val, &d.reg_val);
+  sf::JointTabs& jt = d.jt;
+  jt.J = t.J; jt.S = t.S; jt.num_levels = t.num_levels(); jt.adj_last_level = t.adj_last_level;
+  jt.P = t.P; jt.Kp = t.Kp;
+  up(t.parents, &jt.parents);
+  up(t.fk_js, &jt.fk_js);
+  up(t.fk_level_start, &jt.fk_level_start);
+  up(t.cas_start, &jt.cas_start);
+  up(t.cas_flat, &jt.cas_flat);
+  up(t.part_type, &jt.part_type);
+  up(t.toe_src, &jt.toe_src);
+  up(t.adj_level_start, &jt.adj_level_start);
+  up(t.adj_parts, &jt.adj_parts);
+  up(t.j_ext, &jt.j_ext);
+  up(t.bone_ext, &jt.bone_ext);
+  if (rc != 0) {
+    smplfit_destroy(h);
+    return rc;
+  }
+  h->has_device = true;
+  *out = h;
+  return SMPLFIT_OK;
+}
+
+void smplfit_destroy(smplfit_handle* h) {
+  if (!h) return;
+  for (void* p : h->allocs) (void)hipFree(p);
+  delete h;
+}
+
+int smplfit_get_info(const smplfit_handle* h, smplfit_info* info) {
+  if (!h || !info) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_get_info: null argument");
+  const sf::HostTables& t = h->t;
+  info->num_vertices = t.V;
+  info->num_joints = t.J;
+  info->num_betas = t.S;
+  info->padded_vertices = t.Vp;
+  info->num_used_vertices = t.n_used;
+  info->skin_width = t.KW;
+  info->num_segments = (int)t.segments.size();
+  info->num_fk_levels = t.num_levels();
+  info->adj_last_level = t.adj_last_level;
+  info->has_device = h->has_device ? 1 : 0;
+  return SMPLFIT_OK;
+}
+
+int smplfit_get_table(const smplfit_handle* h, int table_id, int32_t* dst, size_t cap, size_t* n) {
+  if (!h || !n) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_get_table: null argument");
+  const sf::HostTables& t = h->t;
+  std::vector<int32_t> tmp;
+  const std::vector<int32_t>* src = nullptr;
+  switch (table_id) {
+    case SMPLFIT_TAB_PART_ASSIGNMENT: src = &t.part_assignment; break;
+    case SMPLFIT_TAB_SORT_PERM: src = &t.perm; break;
+    case SMPLFIT_TAB_PART_TYPE: src = &t.part_type; break;
+    case SMPLFIT_TAB_FK_ORDER: src = &t.fk_js; break;
+    case SMPLFIT_TAB_FK_LEVEL_START: src = &t.fk_level_start; break;
+    case SMPLFIT_TAB_ADJ_FLAG: src = &t.adj_flag; break;
+    case SMPLFIT_TAB_USED_PART: src = &t.used_part; break;
+    case SMPLFIT_TAB_SEGMENTS:
+      for (auto& s : t.segments) {
+        tmp.push_back(s.start);
+        tmp.push_back(s.count);
+        tmp.push_back(s.part);
+      }
+      src = &tmp;
+      break;
+    default: return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_get_table: unknown table id");
+  }
+  *n = src->size();
+  if (dst) std::memcpy(dst, src->data(), std::min(cap, src->size()) * sizeof(int32_t));
+  return SMPLFIT_OK;
+}
+
+size_t smplfit_workspace_bytes(const smplfit_handle* h, int batch) {
+  if (!h || batch <= 0) return 0;
+  return carve(h->t, batch, nullptr, nullptr);
+}
+
+int smplfit_fit_f32(const smplfit_handle* h, const float* target_vertices,
+                    const float* target_joints, const float* vertex_weights,
+                    const float* joint_weights, int batch, int num_iter, float beta_regularizer,
+                    float beta_regularizer2, int final_adjust_rots, float* pose_rotvecs,
+                    float* shape_betas, float* trans, float* orientations, void* workspace,
+                    size_t workspace_bytes, void* hip_stream) {
+  int rc = check_common(h, batch, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (!target_vertices || !pose_rotvecs || !shape_betas || !trans)
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_f32: null input/output pointer");
+  if (num_iter < 1) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_f32: num_iter must be >= 1");
+  Workspace ws;
+  carve(h->t, batch, (char*)workspace, &ws);
+  FitOptions o{num_iter, beta_regularizer, beta_regularizer2, final_adjust_rots ? 1 : 0, 0};
+  return run_fit(h, target_vertices, target_joints, vertex_weights, joint_weights, batch, o,
+                 pose_rotvecs, shape_betas, trans, orientations, ws, (hipStream_t)hip_stream);
+}
+
+int smplfit_part_rotations_f32(const smplfit_handle* h, const float* target_vertices,
+                               const float* target_joints, const float* vertex_weights,
+                               const float* joint_weights, int batch, float* glob_rotmats,
+                               void* workspace, size_t workspace_bytes, void* hip_stream) {
+  int rc = check_common(h, batch, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (!target_vertices || !glob_rotmats)
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_part_rotations_f32: null pointer");
+  Workspace ws;
+  carve(h->t, batch, (char*)workspace, &ws);
+  FitOptions o{1, 0.f, 0.f, 0, 1};
+  return run_fit(h, target_vertices, target_joints, vertex_weights, joint_weights, batch, o, nullptr,
+                 nullptr, nullptr, glob_rotmats, ws, (hipStream_t)hip_stream);
+}
+
+int smplfit_forward_f32(const smplfit_handle* h, const float* pose_rotvecs,
+                        const float* glob_rotmats, const float* shape_betas, int num_betas_given,
+                        const float* trans, int batch, float* vertices, float* joints,
+                        float* orientations, void* workspace, size_t workspace_bytes,
+                        void* hip_stream) {
+  int rc = check_common(h, batch, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (pose_rotvecs && glob_rotmats)
+    return fail(SMPLFIT_ERR_BAD_ARG, "Only one rotation input may be provided");
+  if (!joints) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_forward_f32: joints output is required");
+  const DevModel& d = h->d;
+  hipStream_t st = (hipStream_t)hip_stream;
+  Workspace ws;
+  carve(h->t, batch, (char*)workspace, &ws);
+  ForwardArgs fa{};
+  fa.pose = pose_rotvecs;
+  fa.glob = glob_rotmats;
+  fa.betas = shape_betas;
+  fa.nb = shape_betas ? std::min(num_betas_given, d.S) : 0;
+  if (shape_betas && num_betas_given > d.S)
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_forward_f32: more betas than the model holds; slice first");
+  fa.trans = trans;
+  fa.joints = joints;
+  fa.orient = orientations;
+  hipLaunchKernelGGL(k_forward_joint, dim3(batch), dim3(64), joint_lds(d), st, d, fa, ws);
+  if (vertices) {
+    launch_gemm(d, ws, batch, st);
+#define SF_CALL_LBS(S_, KW_) launch_lbs<S_, KW_, 2>(d, ws, batch, false, fa.nb, shape_betas, trans, vertices, st)
+    SF_DISPATCH_SKW(d, SF_CALL_LBS);
+#undef SF_CALL_LBS
+  }
+  return post_launch_check();
+}
+
+int smplfit_shape_solve_f32(const smplfit_handle* h, const float* glob_rotmats,
+                            const float* target_vertices, const float* target_joints,
+                            const float* vertex_weights, const float* joint_weights, int batch,
+                            float beta_regularizer, float beta_regularizer2, float* shape_betas,
+                            float* trans, float* vertices_out, float* joints_out, void* workspace,
+                            size_t workspace_bytes, void* hip_stream) {
+  int rc = check_common(h, batch, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (!glob_rotmats || !target_vertices || !shape_betas || !trans)
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_shape_solve_f32: null pointer");
+  const DevModel& d = h->d;
+  hipStream_t st = (hipStream_t)hip_stream;
+  Workspace ws;
+  carve(h->t, batch, (char*)workspace, &ws);
+  const bool joints = target_joints != nullptr;
+  const bool eff_v = joints ? (vertex_weights && joint_weights) : (vertex_weights != nullptr);
+  const bool eff_j = joints && vertex_weights && joint_weights;
+  const size_t lds0 = ((size_t)4 * d.J * sf::kPsum + 20) * 4;
+  if (vertex_weights)
+    hipLaunchKernelGGL((k_center_sort_partsum<true>), dim3(batch), dim3(256), lds0, st, d,
+                       target_vertices, target_joints, vertex_weights, ws);
+  else
+    hipLaunchKernelGGL((k_center_sort_partsum<false>), dim3(batch), dim3(256), lds0, st, d,
+                       target_vertices, target_joints, vertex_weights, ws);
+  JointStageArgs ja{};
+  ja.tj = joints ? ws.tjc : ws.tjreg;  // unused without the joint block
+  ja.rj = nullptr;
+  ja.rj_shared = 1;
+  ja.Gprev = glob_rotmats;
+  ja.jw = joint_weights;
+  ja.fit_rotations = 0;
+  ja.do_prologue = 1;
+  ja.joint_block = joints ? 1 : 0;
+  ja.joint_block_weighted = eff_j ? 1 : 0;
+  if (!joints) hipMemsetAsync(ws.tjreg, 0, (size_t)batch * d.J * 3 * 4, st);
+  hipLaunchKernelGGL(k_joint_stage, dim3(batch), dim3(64), joint_lds(d), st, d, ja, ws);
+  launch_gemm(d, ws, batch, st);
+#define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, batch, eff_v, st)
+  SF_DISPATCH_SKW(d, SF_CALL_ACCUM);
+#undef SF_CALL_ACCUM
+  hipLaunchKernelGGL(k_shape_solve, dim3(batch), dim3(64), joint_lds(d), st, d, ws, beta_regularizer,
+                     beta_regularizer2);
+  hipLaunchKernelGGL(k_copy, dim3(64), dim3(256), 0, st, ws.beta, shape_betas, (size_t)batch * d.S);
+  hipLaunchKernelGGL(k_copy, dim3(64), dim3(256), 0, st, ws.trans, trans, (size_t)batch * 3);
+  if (joints_out)
+    hipLaunchKernelGGL(k_copy, dim3(64), dim3(256), 0, st, ws.rjoints, joints_out,
+                       (size_t)batch * d.J * 3);
+  if (vertices_out) {
+#define SF_CALL_LBS(S_, KW_) launch_lbs<S_, KW_, 2>(d, ws, batch, false, d.S, ws.beta, ws.trans, vertices_out, st)
+    SF_DISPATCH_SKW(d, SF_CALL_LBS);
+#undef SF_CALL_LBS
+  }
+  return post_launch_check();
+}
+
+int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, int reps,
+                            void* workspace, size_t workspace_bytes, void* hip_stream,
+                            float* avg_ms) {
+  int rc = check_common(h, batch, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (!avg_ms || reps < 1) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_time_kernel_f32: bad argument");
+  const DevModel& d = h->d;
+  hipStream_t st = (hipStream_t)hip_stream;
+  Workspace ws;
+  carve(h->t, batch, (char*)workspace, &ws);
+  hipEvent_t e0, e1;
+  SF_HIP_TRY(hipEventCreate(&e0));
+  SF_HIP_TRY(hipEventCreate(&e1));
+  auto once = [&]() -> int {
+    switch (kernel_id) {
+      case SMPLFIT_KERNEL_POSEDIRS_GEMM: return launch_gemm(d, ws, batch, st);
+      case SMPLFIT_KERNEL_SHAPE_ACCUM: {
+#define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, batch, false, st)
+        SF_DISPATCH_SKW(d, SF_CALL_ACCUM);
+#undef SF_CALL_ACCUM
+        return 0;
+      }
+      case SMPLFIT_KERNEL_SHAPE_SOLVE:
+        hipLaunchKernelGGL(k_shape_solve, dim3(batch), dim3(64), joint_lds(d), st, d, ws, 1.0f, 0.0f);
+        return 0;
+      case SMPLFIT_KERNEL_LBS_PARTSUM: {
+#define SF_CALL_LBS(S_, KW_) launch_lbs<S_, KW_, 0>(d, ws, batch, false, d.S, ws.beta, ws.trans, nullptr, st)
+        SF_DISPATCH_SKW(d, SF_CALL_LBS);
+#undef SF_CALL_LBS
+        return 0;
+      }
+      default: return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_time_kernel_f32: unknown kernel id");
+    }
+  };
+  rc = once();  // warm-up
+  if (rc) return rc;
+  SF_HIP_TRY(hipEventRecord(e0, st));
+  for (int r = 0; r < reps; ++r) once();
+  SF_HIP_TRY(hipEventRecord(e1, st));
+  SF_HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  SF_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_ms = ms / (float)reps;
+  return post_launch_check();
+}
+
+}  // extern "C"

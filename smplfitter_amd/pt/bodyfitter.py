@@ -1,0 +1,171 @@
+"""``BodyFitter`` — same surface as ``smplfitter.pt.BodyFitter`` (reference
+src/smplfitter/pt/bodyfitter.py:15-549); ``fit`` in its default configuration runs entirely in the HIP
+kernels behind ``smplfit_fit_f32``.  Options the kernels do not implement raise
+``NotImplementedError`` — they never silently compute something else.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .bodymodel import BodyModel, _ptr
+
+
+class BodyFitter(nn.Module):
+    """Fits SMPL-family parameters (pose, shape, translation) to target vertices (and joints).
+
+    Parameters:
+        body_model: the :class:`BodyModel` to fit.
+        enable_kid: accepted for signature compatibility; the kid blend shape is not implemented
+            by the HIP kernels (``fit`` raises ``NotImplementedError`` when it is set).
+    """
+
+    def __init__(self, body_model: BodyModel, enable_kid: bool = False):
+        super().__init__()
+        self.body_model = body_model
+        self.n_betas = body_model.shapedirs.shape[2]
+        self.enable_kid = enable_kid
+        self.is_smpl_family = body_model.model_name.startswith('smpl')
+
+    def _check_options(self, share_beta, scale_target, scale_fit, initial_pose_rotvecs,
+                       initial_shape_betas, initial_kid_factor):
+        if scale_target and scale_fit:  # same check, same message as pt/bodyfitter.py:858-859
+            raise ValueError('Only one of estim_scale_target and estim_scale_fit can be True')
+        unsupported = []
+        if self.enable_kid:
+            unsupported.append('enable_kid')
+        if share_beta:
+            unsupported.append('share_beta')
+        if scale_target or scale_fit:
+            unsupported.append('scale_target/scale_fit')
+        if initial_pose_rotvecs is not None or initial_shape_betas is not None or initial_kid_factor is not None:
+            unsupported.append('initial_* warm start')
+        if unsupported:
+            raise NotImplementedError(
+                'not implemented by the HIP fit kernels (reference falls back to _fit_shape_general, '
+                'pt/bodyfitter.py:1104-1319): ' + ', '.join(unsupported)
+            )
+
+    def fit(
+        self,
+        target_vertices: torch.Tensor,
+        target_joints: Optional[torch.Tensor] = None,
+        vertex_weights: Optional[torch.Tensor] = None,
+        joint_weights: Optional[torch.Tensor] = None,
+        num_iter: int = 1,
+        beta_regularizer: float = 1,
+        beta_regularizer2: float = 0,
+        scale_regularizer: float = 0,
+        kid_regularizer: Optional[float] = None,
+        share_beta: bool = False,
+        final_adjust_rots: bool = True,
+        scale_target: bool = False,
+        scale_fit: bool = False,
+        initial_pose_rotvecs: Optional[torch.Tensor] = None,
+        initial_shape_betas: Optional[torch.Tensor] = None,
+        initial_kid_factor: Optional[torch.Tensor] = None,
+        requested_keys: Optional[list[str]] = None,
+        _workspace: Optional[torch.Tensor] = None,
+    ) -> dict[str, torch.Tensor]:
+        """Same arguments and returned keys as the reference's ``fit`` (pt/bodyfitter.py:283-549):
+        ``shape_betas, trans, orientations, relative_orientations`` and ``pose_rotvecs`` when
+        requested (default)."""
+        if requested_keys is None:
+            requested_keys = ['pose_rotvecs']
+        self._check_options(share_beta, scale_target, scale_fit, initial_pose_rotvecs,
+                            initial_shape_betas, initial_kid_factor)
+        bm = self.body_model
+        device = bm.v_template.device
+        for t in (target_vertices, target_joints, vertex_weights, joint_weights):
+            if t is not None and t.requires_grad:
+                raise NotImplementedError('the HIP fit kernels are not differentiable; detach the inputs')
+        J, V, S = bm.num_joints, bm.num_vertices, self.n_betas
+        if target_vertices.ndim != 3 or tuple(target_vertices.shape[1:]) != (V, 3):
+            raise ValueError(f'target_vertices must have shape (batch, {V}, 3), got {tuple(target_vertices.shape)}')
+        B = target_vertices.shape[0]
+        prep = lambda t: None if t is None else t.to(device=device, dtype=torch.float32).contiguous()  # noqa: E731
+        tv, tj, vw, jw = prep(target_vertices), prep(target_joints), prep(vertex_weights), prep(joint_weights)
+        if tj is not None and tuple(tj.shape) != (B, J, 3):
+            raise ValueError(f'target_joints must have shape ({B}, {J}, 3), got {tuple(tj.shape)}')
+        if vw is not None and tuple(vw.shape) != (B, V):
+            raise ValueError(f'vertex_weights must have shape ({B}, {V})')
+        if jw is not None and tuple(jw.shape) != (B, J):
+            raise ValueError(f'joint_weights must have shape ({B}, {J})')
+        pose = torch.empty((B, 3 * J), dtype=torch.float32, device=device)
+        betas = torch.empty((B, S), dtype=torch.float32, device=device)
+        trans = torch.empty((B, 3), dtype=torch.float32, device=device)
+        orient = torch.empty((B, J, 3, 3), dtype=torch.float32, device=device)
+        if B > 0:
+            h = bm._native(device)
+            ws = _workspace if _workspace is not None else bm._workspace(h, B, device)
+            with torch.cuda.device(device):
+                stream = torch.cuda.current_stream(device).cuda_stream
+                _lib.check(_lib.load().smplfit_fit_f32(
+                    h.ptr, _ptr(tv), _ptr(tj), _ptr(vw), _ptr(jw), B, int(num_iter),
+                    float(beta_regularizer), float(beta_regularizer2), int(bool(final_adjust_rots)),
+                    _ptr(pose), _ptr(betas), _ptr(trans), _ptr(orient), _ptr(ws), ws.numel(),
+                    C.c_void_p(stream)))
+        result = dict(shape_betas=betas, trans=trans, orientations=orient)
+        # relative orientations = parent^T @ global (pt/bodyfitter.py:523-533); returned always
+        # (the reference returns the pre-refinement ones when neither rotation key is requested)
+        parents = bm.kintree_parents_tensor[1:].to(device)
+        parent_glob = torch.cat(
+            [torch.eye(3, device=device).expand(B, 1, 3, 3), orient.index_select(1, parents)], dim=1
+        )
+        result['relative_orientations'] = parent_glob.transpose(-1, -2) @ orient
+        if 'pose_rotvecs' in requested_keys:
+            result['pose_rotvecs'] = pose
+        return result
+
+    def fit_with_known_pose(self, *args, **kwargs):
+        raise NotImplementedError('fit_with_known_pose is not implemented yet (pt/bodyfitter.py:552-653)')
+
+    def fit_with_known_shape(self, *args, **kwargs):
+        raise NotImplementedError('fit_with_known_shape is not implemented yet (pt/bodyfitter.py:656-838)')
+
+    # -- stage entry points, used by the parity tests ---------------------------------------------
+    def _part_rotations(self, target_vertices, target_joints=None, vertex_weights=None, joint_weights=None):
+        """Global part rotations of the first rotation pass (centring included)."""
+        bm = self.body_model
+        device = bm.v_template.device
+        prep = lambda t: None if t is None else t.to(device=device, dtype=torch.float32).contiguous()  # noqa: E731
+        tv, tj, vw, jw = prep(target_vertices), prep(target_joints), prep(vertex_weights), prep(joint_weights)
+        B = tv.shape[0]
+        G = torch.empty((B, bm.num_joints, 3, 3), dtype=torch.float32, device=device)
+        h = bm._native(device)
+        ws = bm._workspace(h, B, device)
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            _lib.check(_lib.load().smplfit_part_rotations_f32(
+                h.ptr, _ptr(tv), _ptr(tj), _ptr(vw), _ptr(jw), B, _ptr(G), _ptr(ws), ws.numel(),
+                C.c_void_p(stream)))
+        return G
+
+    def _shape_solve(self, glob_rotmats, target_vertices, target_joints=None, vertex_weights=None,
+                     joint_weights=None, beta_regularizer=1.0, beta_regularizer2=0.0):
+        """One shape solve for given global rotations; targets are centred internally and the
+        returned trans / vertices / joints live in the centred frame."""
+        bm = self.body_model
+        device = bm.v_template.device
+        prep = lambda t: None if t is None else t.to(device=device, dtype=torch.float32).contiguous()  # noqa: E731
+        G, tv, tj = prep(glob_rotmats), prep(target_vertices), prep(target_joints)
+        vw, jw = prep(vertex_weights), prep(joint_weights)
+        B, J, V, S = tv.shape[0], bm.num_joints, bm.num_vertices, self.n_betas
+        betas = torch.empty((B, S), dtype=torch.float32, device=device)
+        trans = torch.empty((B, 3), dtype=torch.float32, device=device)
+        verts = torch.empty((B, V, 3), dtype=torch.float32, device=device)
+        joints = torch.empty((B, J, 3), dtype=torch.float32, device=device)
+        h = bm._native(device)
+        ws = bm._workspace(h, B, device)
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            _lib.check(_lib.load().smplfit_shape_solve_f32(
+                h.ptr, _ptr(G), _ptr(tv), _ptr(tj), _ptr(vw), _ptr(jw), B, float(beta_regularizer),
+                float(beta_regularizer2), _ptr(betas), _ptr(trans), _ptr(verts), _ptr(joints),
+                _ptr(ws), ws.numel(), C.c_void_p(stream)))
+        return dict(shape_betas=betas, trans=trans, vertices=verts, joints=joints)

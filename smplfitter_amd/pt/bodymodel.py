@@ -1,0 +1,198 @@
+"""``BodyModel`` — same surface as ``smplfitter.pt.BodyModel`` (reference
+src/smplfitter/pt/bodymodel.py:12-453), with ``forward`` dispatched to the HIP LBS kernels through the
+C-ABI (``smplfit_forward_f32``).  PyTorch tensors are containers only: device memory + stream.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib, modelio
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class BodyModel(nn.Module):
+    """Statistical body model of the SMPL family (forward = blend shapes + FK + linear blend
+    skinning).  Constructor arguments, buffers and attributes follow the reference
+    (pt/bodymodel.py:53-119)."""
+
+    def __init__(
+        self,
+        model_name: str = 'smpl',
+        gender: str = 'neutral',
+        model_root: Optional[str] = None,
+        num_betas: Optional[int] = None,
+        vertex_subset_size: Optional[int] = None,
+        vertex_subset=None,
+        faces=None,
+        joint_regressor_post_lbs=None,
+        device=None,
+    ):
+        super().__init__()
+        self.gender = gender
+        self.model_name = model_name
+        if isinstance(vertex_subset, torch.Tensor):
+            vertex_subset = vertex_subset.cpu().numpy()
+        data = modelio.load_model(
+            model_name, gender, model_root, num_betas, vertex_subset_size, vertex_subset, faces,
+            joint_regressor_post_lbs,
+        )
+        f32 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)  # noqa: E731
+        self.v_template = nn.Buffer(f32(data.v_template))
+        self.shapedirs = nn.Buffer(f32(data.shapedirs))
+        self.posedirs = nn.Buffer(f32(data.posedirs))
+        self.J_regressor_post_lbs = nn.Buffer(f32(data.J_regressor_post_lbs))
+        self.J_template = nn.Buffer(f32(data.J_template))
+        self.J_shapedirs = nn.Buffer(f32(data.J_shapedirs))
+        self.kid_shapedir = nn.Buffer(f32(data.kid_shapedir))
+        self.kid_J_shapedir = nn.Buffer(f32(data.kid_J_shapedir))
+        self.weights = nn.Buffer(f32(data.weights))
+        self.kintree_parents_tensor = nn.Buffer(torch.tensor(data.kintree_parents, dtype=torch.int64))
+        self.kintree_parents = data.kintree_parents
+        self.faces = data.faces
+        self.num_joints = data.num_joints
+        self.num_vertices = data.num_vertices
+        self.num_betas = self.shapedirs.shape[2]
+        self.vertex_subset = data.vertex_subset
+        self.joint_names = data.joint_names
+        if self.vertex_subset is None:
+            self.vertex_subset = np.arange(self.num_vertices)
+        self._handles = {}  # device index -> _lib.Handle (model constants uploaded to that GPU)
+        if device is not None:
+            self.to(device)
+
+    # -- native handle ---------------------------------------------------------------------------
+    def _native(self, device: torch.device) -> _lib.Handle:
+        """The C-ABI handle holding this model's constants on ``device`` (created on first use)."""
+        if device.type != 'cuda':
+            raise RuntimeError(
+                'smplfitter_amd runs on MI355X through its HIP kernels only: move the model and the '
+                "inputs to a 'cuda' (ROCm) device. There is no CPU path."
+            )
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        h = self._handles.get(idx)
+        if h is None:
+            reg = self.J_regressor_post_lbs
+            desc, keep = _lib.make_desc(
+                self.v_template.cpu().numpy(), self.shapedirs.cpu().numpy(),
+                self.posedirs.cpu().numpy(), self.weights.cpu().numpy(),
+                self.J_template.cpu().numpy(), self.J_shapedirs.cpu().numpy(), self.kintree_parents,
+                reg.cpu().numpy() if reg.shape[1] == self.num_vertices else None,
+                is_smpl_family=self.model_name.startswith('smpl'),
+            )
+            with torch.cuda.device(idx):
+                h = _lib.Handle(desc)
+            self._handles[idx] = h
+        return h
+
+    @staticmethod
+    def _workspace(h: _lib.Handle, batch: int, device) -> torch.Tensor:
+        return torch.empty(h.workspace_bytes(batch), dtype=torch.uint8, device=device)
+
+    # -- forward ---------------------------------------------------------------------------------
+    def forward(
+        self,
+        pose_rotvecs: Optional[torch.Tensor] = None,
+        shape_betas: Optional[torch.Tensor] = None,
+        trans: Optional[torch.Tensor] = None,
+        kid_factor: Optional[torch.Tensor] = None,
+        rel_rotmats: Optional[torch.Tensor] = None,
+        glob_rotmats: Optional[torch.Tensor] = None,
+        return_vertices: bool = True,
+    ) -> dict[str, torch.Tensor]:
+        """Vertices, joints and global orientations for a batch (pt/bodymodel.py:121-307)."""
+        n_rot = sum(x is not None for x in (pose_rotvecs, rel_rotmats, glob_rotmats))
+        if n_rot > 1:
+            raise ValueError(
+                'Only one rotation input may be provided '
+                '(pose_rotvecs, rel_rotmats, or glob_rotmats).'
+            )
+        for name, arg, min_ndim in [
+            ('pose_rotvecs', pose_rotvecs, 2), ('shape_betas', shape_betas, 2), ('trans', trans, 2),
+            ('kid_factor', kid_factor, 1), ('rel_rotmats', rel_rotmats, 4),
+            ('glob_rotmats', glob_rotmats, 4),
+        ]:
+            if arg is not None:
+                if isinstance(arg, np.ndarray):
+                    raise TypeError(
+                        f"Expected torch.Tensor for '{name}', got numpy.ndarray. "
+                        f'Convert with torch.from_numpy() or torch.as_tensor().'
+                    )
+                if arg.ndim < min_ndim:
+                    raise ValueError(
+                        f"Expected batched input for '{name}' with at least "
+                        f'{min_ndim} dimensions, but got shape {tuple(arg.shape)}. '
+                        f'For single (unbatched) inputs, use model.single() instead.'
+                    )
+        if kid_factor is not None:
+            raise NotImplementedError('kid_factor is not implemented by the HIP forward kernel yet')
+        device = self.v_template.device
+        J, V = self.num_joints, self.num_vertices
+        batch = 0
+        for arg in (pose_rotvecs, shape_betas, trans, rel_rotmats, glob_rotmats):
+            if arg is not None:
+                batch = arg.shape[0]
+                break
+        if batch == 0:
+            res = dict(
+                joints=torch.empty((0, J, 3), device=device),
+                orientations=torch.empty((0, J, 3, 3), device=device),
+            )
+            if return_vertices:
+                res['vertices'] = torch.empty((0, V, 3), device=device)
+            return res
+        prep = lambda t: None if t is None else t.to(device=device, dtype=torch.float32).contiguous()  # noqa: E731
+        if rel_rotmats is not None:
+            # relative -> global rotations: FK of rotation matrices (host-side glue, J small matmuls;
+            # pt/bodymodel.py:230-234), then the glob_rotmats entry of the kernel
+            rel = prep(rel_rotmats)
+            glob = [rel[:, 0]]
+            for i in range(1, J):
+                glob.append(glob[self.kintree_parents[i]] @ rel[:, i])
+            glob_rotmats = torch.stack(glob, dim=1)
+        pose = prep(pose_rotvecs.reshape(batch, J * 3)) if pose_rotvecs is not None else None
+        glob = prep(glob_rotmats)
+        betas = prep(shape_betas)
+        nb = 0
+        if betas is not None:
+            nb = min(betas.shape[1], self.num_betas)
+            betas = betas[:, :nb].contiguous()
+            if nb == 0:
+                betas = None
+        tr = prep(trans)
+        if tr is not None and tr.shape[0] != batch:
+            tr = tr.expand(batch, 3).contiguous()
+        h = self._native(device)
+        ws = self._workspace(h, batch, device)
+        joints = torch.empty((batch, J, 3), dtype=torch.float32, device=device)
+        orient = torch.empty((batch, J, 3, 3), dtype=torch.float32, device=device)
+        verts = torch.empty((batch, V, 3), dtype=torch.float32, device=device) if return_vertices else None
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            _lib.check(_lib.load().smplfit_forward_f32(
+                h.ptr, _ptr(pose), _ptr(glob), _ptr(betas), nb, _ptr(tr), batch, _ptr(verts),
+                _ptr(joints), _ptr(orient), _ptr(ws), ws.numel(), C.c_void_p(stream)))
+        res = dict(joints=joints, orientations=orient)
+        if return_vertices:
+            res['vertices'] = verts
+        return res
+
+    def single(self, pose_rotvecs=None, shape_betas=None, trans=None, kid_factor=None,
+               rel_rotmats=None, glob_rotmats=None, return_vertices: bool = True):
+        """Unbatched ``forward`` (pt/bodymodel.py:310-380)."""
+        u = lambda t: t.unsqueeze(0) if t is not None else None  # noqa: E731
+        if all(x is None for x in (pose_rotvecs, shape_betas, trans, rel_rotmats, glob_rotmats)):
+            shape_betas = torch.zeros((0,), dtype=torch.float32, device=self.v_template.device)
+            pose_rotvecs = torch.zeros((self.num_joints * 3,), dtype=torch.float32,
+                                       device=self.v_template.device)
+        res = self.forward(u(pose_rotvecs), u(shape_betas), u(trans), kid_factor, u(rel_rotmats),
+                           u(glob_rotmats), return_vertices)
+        return {k: v.squeeze(0) for k, v in res.items()}

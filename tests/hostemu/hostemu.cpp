@@ -1,0 +1,333 @@
+// TEST-ONLY host emulation of the HIP pipeline (never shipped, never loaded by the package).
+//
+// The device code keeps its arithmetic in headers shared with this file (csrc/sf_math.h,
+// csrc/sf_stages.h, csrc/sf_tables.cpp): the joint-level stages run here with a one-lane context
+// (lane = 0, n = 1, sync = no-op) and the per-vertex bodies run in plain loops in the same order of
+// kernels as run_fit() in csrc/smplfit_hip.hip.  This lets the build container (no GPU) check the
+// table builder, the stage logic and the orchestration against the oracle and the golden vectors
+// before any GPU minute is spent; wave reductions / LDS staging / MFMA remain GPU-only code that the
+// -m gpu parity tests cover.  Built by tests/test_hostemu.py with g++.
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../smplfitter_amd/csrc/sf_stages.h"
+#include "../../smplfitter_amd/csrc/sf_tables.h"
+
+namespace {
+
+struct HostCtx {
+  int lane = 0, n = 1;
+  void sync() const {}
+};
+
+sf::JointTabs make_tabs(const sf::HostTables& t) {
+  sf::JointTabs jt;
+  jt.J = t.J; jt.S = t.S; jt.num_levels = t.num_levels(); jt.adj_last_level = t.adj_last_level;
+  jt.P = t.P; jt.Kp = t.Kp;
+  jt.parents = t.parents.data(); jt.fk_js = t.fk_js.data();
+  jt.fk_level_start = t.fk_level_start.data(); jt.cas_start = t.cas_start.data();
+  jt.cas_flat = t.cas_flat.data(); jt.part_type = t.part_type.data(); jt.toe_src = t.toe_src.data();
+  jt.adj_level_start = t.adj_level_start.data(); jt.adj_parts = t.adj_parts.data();
+  jt.j_ext = t.j_ext.data(); jt.bone_ext = t.bone_ext.data();
+  return jt;
+}
+
+template <int S, int KW>
+struct Emu {
+  const sf::HostTables& t;
+  sf::JointTabs jt;
+  int B;
+  std::vector<float> tvs, vws, vposed, rp, mean, tjc, psum, G, jd, pext, gramj, beta, trans, jb,
+      rjoints, rverts, tjreg, rjreg, scratch;
+  std::vector<double> gramv;
+  sf::JointScratch sh;
+
+  Emu(const sf::HostTables& tt, int b) : t(tt), jt(make_tabs(tt)), B(b) {
+    const int J = t.J, Vp = t.Vp, NE1 = sf::ne_size(S) + 1;
+    tvs.assign((size_t)B * 3 * Vp, 0.f); vws.assign((size_t)B * Vp, 0.f);
+    vposed.assign((size_t)B * 3 * Vp, 0.f); rp.assign((size_t)B * t.Kp, 0.f);
+    mean.assign(B * 3, 0.f); tjc.assign((size_t)B * J * 3, 0.f);
+    psum.assign((size_t)B * J * sf::kPsum, 0.f); G.assign((size_t)B * J * 9, 0.f);
+    jd.assign((size_t)B * J * sf::jd_stride(S) + 4, 0.f); pext.assign((size_t)B * J * 3 * (S + 1), 0.f);
+    gramj.assign((size_t)B * NE1, 0.f); gramv.assign((size_t)B * NE1, 0.0);
+    beta.assign(B * S, 0.f); trans.assign(B * 3, 0.f); jb.assign((size_t)B * J * 4, 0.f);
+    rjoints.assign((size_t)B * J * 3, 0.f); rverts.assign((size_t)B * 3 * Vp, 0.f);
+    tjreg.assign((size_t)B * J * 3, 0.f); rjreg.assign((size_t)B * J * 3, 0.f);
+    scratch.assign(sf::joint_scratch_floats(J, S) + 8, 0.f);
+    // 16-byte align the scratch base
+    float* base = scratch.data();
+    while ((uintptr_t)base & 15) ++base;
+    sh = sf::carve_joint_scratch(base, J, S);
+  }
+
+  float* jd_b(int b) {  // 16-byte aligned per-instance joint block (stride is a multiple of 4 floats)
+    float* p = jd.data();
+    while ((uintptr_t)p & 15) ++p;
+    return p + (size_t)b * t.J * sf::jd_stride(S);
+  }
+
+  void k0(const float* tv, const float* tj, const float* vw) {
+    const int V = t.V, J = t.J, Vp = t.Vp;
+    for (int b = 0; b < B; ++b) {
+      const float* tvb = tv + (size_t)b * V * 3;
+      float s[3] = {0, 0, 0};
+      for (int v = 0; v < V; ++v) for (int c = 0; c < 3; ++c) s[c] += tvb[v * 3 + c];
+      if (tj) for (int j = 0; j < J; ++j) for (int c = 0; c < 3; ++c) s[c] += tj[((size_t)b * J + j) * 3 + c];
+      const float n = (float)(V + (tj ? J : 0));
+      float mu[3];
+      for (int c = 0; c < 3; ++c) { mu[c] = s[c] / n; mean[b * 3 + c] = mu[c]; }
+      if (tj) for (int k = 0; k < J * 3; ++k) tjc[(size_t)b * J * 3 + k] = tj[(size_t)b * J * 3 + k] - mu[k % 3];
+      float* ps = psum.data() + (size_t)b * J * sf::kPsum;
+      std::fill(ps, ps + J * sf::kPsum, 0.f);
+      for (int i = 0; i < Vp; ++i) {
+        const int o = t.perm[i];
+        float tt[3] = {0, 0, 0}, w = 0.f;
+        if (o >= 0) {
+          for (int c = 0; c < 3; ++c) tt[c] = tvb[o * 3 + c] - mu[c];
+          if (vw) w = vw[(size_t)b * V + o];
+        }
+        for (int c = 0; c < 3; ++c) tvs[((size_t)b * 3 + c) * Vp + i] = tt[c];
+        if (vw) vws[(size_t)b * Vp + i] = w;
+        if (i < t.n_used) {
+          const float a[3] = {t.dm[i], t.dm[Vp + i], t.dm[2 * Vp + i]};
+          sf::partsum_vertex(tt, a, vw ? w : 1.f, vw != nullptr, ps + t.slot_part[i] * sf::kPsum);
+        }
+      }
+    }
+  }
+
+  void regress(const float* src, bool shared_src, float* out, int nb) {
+    const int J = t.J, Vp = t.Vp;
+    for (int b = 0; b < nb; ++b) {
+      const float* s = shared_src ? src : src + (size_t)b * 3 * Vp;
+      for (int j = 0; j < J; ++j) {
+        float a[3] = {0, 0, 0};
+        for (int k = t.reg_start[j]; k < t.reg_start[j + 1]; ++k)
+          for (int c = 0; c < 3; ++c) a[c] += t.reg_val[k] * s[c * Vp + t.reg_slot[k]];
+        for (int c = 0; c < 3; ++c) out[((size_t)b * J + j) * 3 + c] = a[c];
+      }
+    }
+  }
+
+  void k1(const float* tj, const float* rj, bool rj_shared, const float* Gprev, const float* jw,
+          bool fit_rot, bool prologue, bool jblock, bool jblock_w) {
+    const int J = t.J, NE1 = sf::ne_size(S) + 1;
+    HostCtx cx;
+    for (int b = 0; b < B; ++b)
+      sf::joint_stage(cx, jt, sh, psum.data() + (size_t)b * J * sf::kPsum, tj + (size_t)b * J * 3,
+                      rj ? (rj_shared ? rj : rj + (size_t)b * J * 3) : nullptr,
+                      Gprev ? Gprev + (size_t)b * J * 9 : nullptr, jw ? jw + (size_t)b * J : nullptr,
+                      fit_rot, prologue, jblock, jblock_w, G.data() + (size_t)b * J * 9,
+                      rp.data() + (size_t)b * t.Kp, jd_b(b), pext.data() + (size_t)b * J * 3 * (S + 1),
+                      gramj.data() + (size_t)b * NE1);
+  }
+
+  void gemm() {  // k-ordered fp32 fma chain per output, like the MFMA path
+    const int N = 3 * t.Vp;
+    for (int b = 0; b < B; ++b)
+      for (int n = 0; n < N; ++n) {
+        float acc = t.vtN[n];
+        for (int k = 0; k < t.P; ++k) acc = fmaf(rp[(size_t)b * t.Kp + k], t.pdT[(size_t)k * N + n], acc);
+        vposed[(size_t)b * N + n] = acc;
+      }
+  }
+
+  void k3(bool weighted) {
+    const int Vp = t.Vp, NE = sf::ne_size(S);
+    for (int b = 0; b < B; ++b) {
+      float acc[sf::ne_size(S) + 1];
+      for (int k = 0; k <= NE; ++k) acc[k] = 0.f;
+      std::vector<double> dacc(NE + 1, 0.0);
+      // accumulate in chunks so fp32 partial sums stay short, like the per-lane partials on the GPU
+      for (int i0 = 0; i0 < Vp; i0 += 32) {
+        for (int k = 0; k <= NE; ++k) acc[k] = 0.f;
+        for (int i = i0; i < i0 + 32 && i < Vp; ++i) {
+          const sf::Skin<KW> sk = sf::load_skin<KW>(t.widx.data(), t.wval.data(), Vp, i);
+          const float vp[3] = {vposed[((size_t)b * 3) * Vp + i], vposed[((size_t)b * 3 + 1) * Vp + i],
+                               vposed[((size_t)b * 3 + 2) * Vp + i]};
+          const float tv[3] = {tvs[((size_t)b * 3) * Vp + i], tvs[((size_t)b * 3 + 1) * Vp + i],
+                               tvs[((size_t)b * 3 + 2) * Vp + i]};
+          float sdv[3 * S];
+          for (int k = 0; k < 3 * S; ++k) sdv[k] = t.sd[(size_t)k * Vp + i];
+          float wv = 1.f;
+          if (weighted) { wv = vws[(size_t)b * Vp + i]; acc[NE] += wv; }
+          if (weighted)
+            sf::shape_accum_vertex<S, KW, true>(jd_b(b), sk, vp, tv, sdv, wv, acc);
+          else
+            sf::shape_accum_vertex<S, KW, false>(jd_b(b), sk, vp, tv, sdv, wv, acc);
+        }
+        for (int k = 0; k <= NE; ++k) dacc[k] += (double)acc[k];
+      }
+      if (!weighted) dacc[NE] = (double)t.V;
+      for (int k = 0; k <= NE; ++k) gramv[(size_t)b * (NE + 1) + k] = dacc[k];
+    }
+  }
+
+  void k4(float reg, float reg2) {
+    const int J = t.J, NE1 = sf::ne_size(S) + 1;
+    HostCtx cx;
+    for (int b = 0; b < B; ++b)
+      sf::solve_stage(cx, jt, sh, gramv.data() + (size_t)b * NE1, gramj.data() + (size_t)b * NE1,
+                      pext.data() + (size_t)b * J * 3 * (S + 1), jd_b(b), reg, reg2,
+                      beta.data() + (size_t)b * S, trans.data() + (size_t)b * 3,
+                      rjoints.data() + (size_t)b * J * 3, jb.data() + (size_t)b * J * 4);
+  }
+
+  void vertex(int b, int i, const float* be, int nb, const float* tr, float* v) {
+    const int Vp = t.Vp;
+    const sf::Skin<KW> sk = sf::load_skin<KW>(t.widx.data(), t.wval.data(), Vp, i);
+    const float vp[3] = {vposed[((size_t)b * 3) * Vp + i], vposed[((size_t)b * 3 + 1) * Vp + i],
+                         vposed[((size_t)b * 3 + 2) * Vp + i]};
+    float sdv[3 * S];
+    for (int k = 0; k < 3 * S; ++k) sdv[k] = t.sd[(size_t)k * Vp + i];
+    float bb[S];
+    for (int s = 0; s < S; ++s) bb[s] = (be && s < nb) ? be[s] : 0.f;
+    alignas(16) float jbl[sf::kMaxJoints * 4];
+    std::memcpy(jbl, jb.data() + (size_t)b * t.J * 4, sizeof(float) * t.J * 4);
+    sf::lbs_vertex<S, KW>(jd_b(b), jbl, sk, vp, sdv, bb, S, tr, v);
+  }
+
+  void k5(bool weighted, bool store) {
+    const int J = t.J, Vp = t.Vp;
+    for (int b = 0; b < B; ++b) {
+      float* ps = psum.data() + (size_t)b * J * sf::kPsum;
+      std::fill(ps, ps + J * sf::kPsum, 0.f);
+      for (int i = 0; i < (store ? t.V : t.n_used); ++i) {
+        float v[3];
+        vertex(b, i, beta.data() + (size_t)b * S, S, trans.data() + (size_t)b * 3, v);
+        if (store) for (int c = 0; c < 3; ++c) rverts[((size_t)b * 3 + c) * Vp + i] = v[c];
+        if (i < t.n_used) {
+          const float tt[3] = {tvs[((size_t)b * 3) * Vp + i], tvs[((size_t)b * 3 + 1) * Vp + i],
+                               tvs[((size_t)b * 3 + 2) * Vp + i]};
+          sf::partsum_vertex(tt, v, weighted ? vws[(size_t)b * Vp + i] : 1.f, weighted,
+                             ps + t.slot_part[i] * sf::kPsum);
+        }
+      }
+    }
+  }
+};
+
+thread_local std::string g_err;
+
+template <int S, int KW>
+int fit_impl(const sf::HostTables& t, const float* tv, const float* tj, const float* vw,
+             const float* jw, int B, int num_iter, float reg, float reg2, int final_adjust,
+             float* pose, float* betas, float* trans, float* orient, float* G0_out) {
+  Emu<S, KW> e(t, B);
+  const bool joints = tj != nullptr;
+  const bool eff_v = joints ? (vw && jw) : (vw != nullptr);
+  const bool eff_j = joints && vw && jw;
+  e.k0(tv, tj, vw);
+  const float* tj_rot = e.tjc.data();
+  std::vector<float> jtemplate((size_t)t.J * 3);
+  for (int k = 0; k < t.J * 3; ++k) jtemplate[k] = t.j_ext[(size_t)k * (S + 1)];
+  std::vector<float> rj0((size_t)t.J * 3);
+  if (!joints) {
+    e.regress(e.tvs.data(), false, e.tjreg.data(), B);
+    tj_rot = e.tjreg.data();
+    e.regress(t.dm.data(), true, rj0.data(), 1);
+  } else {
+    rj0 = jtemplate;
+  }
+  e.k1(tj_rot, rj0.data(), true, nullptr, jw, true, true, joints, eff_j);
+  if (G0_out) std::memcpy(G0_out, e.G.data(), sizeof(float) * (size_t)B * t.J * 9);
+  for (int it = 0; it < num_iter; ++it) {
+    e.gemm();
+    e.k3(eff_v);
+    e.k4(reg, reg2);
+    const bool last = it + 1 == num_iter;
+    if (last && !final_adjust) break;
+    e.k5(vw != nullptr, !joints);
+    if (!joints) e.regress(e.rverts.data(), false, e.rjreg.data(), B);
+    if (last) break;
+    std::vector<float> Gprev = e.G;
+    e.k1(tj_rot, joints ? e.rjoints.data() : e.rjreg.data(), false, Gprev.data(), jw, true, true,
+         joints, eff_j);
+  }
+  HostCtx cx;
+  for (int b = 0; b < B; ++b)
+    sf::refine_stage(cx, e.jt, e.sh, e.psum.data() + (size_t)b * t.J * sf::kPsum,
+                     tj_rot + (size_t)b * t.J * 3,
+                     (joints ? e.rjoints.data() : e.rjreg.data()) + (size_t)b * t.J * 3,
+                     e.rjoints.data() + (size_t)b * t.J * 3, jw ? jw + (size_t)b * t.J : nullptr,
+                     e.G.data() + (size_t)b * t.J * 9, e.beta.data() + (size_t)b * S,
+                     e.trans.data() + (size_t)b * 3, e.mean.data() + (size_t)b * 3, final_adjust != 0,
+                     pose + (size_t)b * t.J * 3, betas + (size_t)b * S, trans + (size_t)b * 3,
+                     orient ? orient + (size_t)b * t.J * 9 : nullptr);
+  return 0;
+}
+
+template <int S, int KW>
+int forward_impl(const sf::HostTables& t, const float* pose, const float* glob, const float* betas,
+                 int nb, const float* trans, int B, float* verts, float* joints, float* orient) {
+  Emu<S, KW> e(t, B);
+  HostCtx cx;
+  const float zero3[3] = {0, 0, 0};
+  for (int b = 0; b < B; ++b) {
+    sf::forward_joint_stage(cx, e.jt, e.sh, pose ? pose + (size_t)b * t.J * 3 : nullptr,
+                            glob ? glob + (size_t)b * t.J * 9 : nullptr,
+                            betas ? betas + (size_t)b * nb : nullptr, betas ? nb : 0,
+                            trans ? trans + (size_t)b * 3 : nullptr, e.rp.data() + (size_t)b * t.Kp,
+                            e.jd_b(b), joints + (size_t)b * t.J * 3,
+                            orient ? orient + (size_t)b * t.J * 9 : nullptr);
+    for (int k = 0; k < t.J * 3; ++k)
+      e.jb[(size_t)b * t.J * 4 + (k / 3) * 4 + k % 3] = e.jd_b(b)[(k / 3) * sf::jd_stride(S) + 9 + k % 3];
+  }
+  if (verts) {
+    e.gemm();
+    for (int b = 0; b < B; ++b)
+      for (int i = 0; i < t.V; ++i) {
+        float v[3];
+        e.vertex(b, i, betas ? betas + (size_t)b * nb : nullptr, nb, trans ? trans + (size_t)b * 3 : zero3, v);
+        for (int c = 0; c < 3; ++c) verts[((size_t)b * t.V + t.perm[i]) * 3 + c] = v[c];
+      }
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* hostemu_last_error() { return g_err.c_str(); }
+
+// proj_so3 / mat2rotvec / rotvec2mat / align_unit_vectors on n inputs (primitive goldens)
+void hostemu_proj_so3(const float* A, float* R, int n) { for (int i = 0; i < n; ++i) sf::proj_so3(A + i * 9, R + i * 9); }
+void hostemu_mat2rotvec(const float* R, float* rv, int n) { for (int i = 0; i < n; ++i) sf::mat2rotvec(R + i * 9, rv + i * 3); }
+void hostemu_rotvec2mat(const float* rv, float* R, int n) { for (int i = 0; i < n; ++i) sf::rotvec2mat(rv + i * 3, R + i * 9); }
+void hostemu_align(const float* a, const float* b, float* R, int n) { for (int i = 0; i < n; ++i) sf::align_unit_vectors(a + i * 3, b + i * 3, R + i * 9); }
+
+int hostemu_fit(const smplfit_model_desc* d, const float* tv, const float* tj, const float* vw,
+                const float* jw, int B, int num_iter, float reg, float reg2, int final_adjust,
+                float* pose, float* betas, float* trans, float* orient, float* G0_out) {
+  sf::HostTables t;
+  bool unsup = false;
+  g_err = sf::build_tables(*d, t, &unsup);
+  if (!g_err.empty()) return -1;
+  if (t.S == 10 && t.KW == 4)
+    return fit_impl<10, 4>(t, tv, tj, vw, jw, B, num_iter, reg, reg2, final_adjust, pose, betas, trans, orient, G0_out);
+  if (t.S == 10 && t.KW == 8)
+    return fit_impl<10, 8>(t, tv, tj, vw, jw, B, num_iter, reg, reg2, final_adjust, pose, betas, trans, orient, G0_out);
+  if (t.S == 16 && t.KW == 4)
+    return fit_impl<16, 4>(t, tv, tj, vw, jw, B, num_iter, reg, reg2, final_adjust, pose, betas, trans, orient, G0_out);
+  g_err = "hostemu: unsupported (S, KW)";
+  return -2;
+}
+
+int hostemu_forward(const smplfit_model_desc* d, const float* pose, const float* glob,
+                    const float* betas, int nb, const float* trans, int B, float* verts,
+                    float* joints, float* orient) {
+  sf::HostTables t;
+  bool unsup = false;
+  g_err = sf::build_tables(*d, t, &unsup);
+  if (!g_err.empty()) return -1;
+  if (t.S == 10 && t.KW == 4) return forward_impl<10, 4>(t, pose, glob, betas, nb, trans, B, verts, joints, orient);
+  if (t.S == 10 && t.KW == 8) return forward_impl<10, 8>(t, pose, glob, betas, nb, trans, B, verts, joints, orient);
+  if (t.S == 16 && t.KW == 4) return forward_impl<16, 4>(t, pose, glob, betas, nb, trans, B, verts, joints, orient);
+  g_err = "hostemu: unsupported (S, KW)";
+  return -2;
+}
+
+}  // extern "C"

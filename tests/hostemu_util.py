@@ -1,0 +1,96 @@
+"""Build + ctypes-load the TEST-ONLY host emulation (tests/hostemu/hostemu.cpp)."""
+
+import ctypes as C
+import os
+import os.path as osp
+import subprocess
+
+import numpy as np
+
+from smplfitter_amd import _lib
+
+HERE = osp.dirname(osp.abspath(__file__))
+SRC = osp.join(HERE, 'hostemu', 'hostemu.cpp')
+CSRC = osp.join(HERE, '..', 'smplfitter_amd', 'csrc')
+BUILD = osp.join(HERE, 'hostemu', '_build')
+SO = osp.join(BUILD, 'libhostemu.so')
+
+_cache = None
+
+
+def load():
+    global _cache
+    if _cache is not None:
+        return _cache
+    deps = [SRC] + [osp.join(CSRC, f) for f in ('sf_math.h', 'sf_stages.h', 'sf_tables.h', 'sf_tables.cpp')]
+    if not osp.exists(SO) or any(osp.getmtime(d) > osp.getmtime(SO) for d in deps):
+        os.makedirs(BUILD, exist_ok=True)
+        tmp = SO + f'.tmp{os.getpid()}'
+        subprocess.run(
+            ['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', SRC,
+             osp.join(CSRC, 'sf_tables.cpp'), '-o', tmp],
+            check=True,
+        )
+        os.replace(tmp, SO)
+    lib = C.CDLL(SO)
+    vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
+    lib.hostemu_fit.argtypes = [C.POINTER(_lib.ModelDesc), vp, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp, vp, vp, vp]
+    lib.hostemu_fit.restype = i32
+    lib.hostemu_forward.argtypes = [C.POINTER(_lib.ModelDesc), vp, vp, vp, i32, vp, i32, vp, vp, vp]
+    lib.hostemu_forward.restype = i32
+    lib.hostemu_last_error.restype = C.c_char_p
+    for fn in ('hostemu_proj_so3', 'hostemu_mat2rotvec', 'hostemu_rotvec2mat'):
+        getattr(lib, fn).argtypes = [vp, vp, i32]
+    lib.hostemu_align.argtypes = [vp, vp, vp, i32]
+    _cache = lib
+    return lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def desc_from_md(md, kind='smpl'):
+    return _lib.make_desc(
+        md.v_template, md.shapedirs, md.posedirs, md.weights, md.J_template, md.J_shapedirs,
+        md.kintree_parents,
+        md.J_regressor_post_lbs if md.J_regressor_post_lbs.shape[1] == md.num_vertices else None,
+        is_smpl_family=kind.startswith('smpl'),
+    )
+
+
+def fit(md, kind, tv, tj=None, vw=None, jw=None, num_iter=1, beta_regularizer=1.0,
+        beta_regularizer2=0.0, final_adjust_rots=True):
+    lib = load()
+    desc, keep = desc_from_md(md, kind)
+    f = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)  # noqa: E731
+    tv, tj, vw, jw = f(tv), f(tj), f(vw), f(jw)
+    B, J, S = tv.shape[0], md.num_joints, md.shapedirs.shape[2]
+    pose = np.zeros((B, 3 * J), np.float32)
+    betas = np.zeros((B, S), np.float32)
+    trans = np.zeros((B, 3), np.float32)
+    orient = np.zeros((B, J, 3, 3), np.float32)
+    G0 = np.zeros((B, J, 3, 3), np.float32)
+    rc = lib.hostemu_fit(C.byref(desc), _p(tv), _p(tj), _p(vw), _p(jw), B, num_iter, beta_regularizer,
+                         beta_regularizer2, int(final_adjust_rots), _p(pose), _p(betas), _p(trans),
+                         _p(orient), _p(G0))
+    if rc != 0:
+        raise RuntimeError(lib.hostemu_last_error().decode())
+    return dict(pose_rotvecs=pose, shape_betas=betas, trans=trans, orientations=orient, glob_rotmats_iter0=G0)
+
+
+def forward(md, kind, pose=None, betas=None, trans=None, glob=None):
+    lib = load()
+    desc, keep = desc_from_md(md, kind)
+    f = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)  # noqa: E731
+    pose, betas, trans, glob = f(pose), f(betas), f(trans), f(glob)
+    B = (pose if pose is not None else glob).shape[0]
+    J, V = md.num_joints, md.num_vertices
+    verts = np.zeros((B, V, 3), np.float32)
+    joints = np.zeros((B, J, 3), np.float32)
+    orient = np.zeros((B, J, 3, 3), np.float32)
+    rc = lib.hostemu_forward(C.byref(desc), _p(pose), _p(glob), _p(betas), 0 if betas is None else betas.shape[1],
+                             _p(trans), B, _p(verts), _p(joints), _p(orient))
+    if rc != 0:
+        raise RuntimeError(lib.hostemu_last_error().decode())
+    return dict(vertices=verts, joints=joints, orientations=orient)

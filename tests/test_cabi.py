@@ -1,0 +1,97 @@
+"""The C-ABI library loads here (no GPU) and exports every symbol include/smplfit.h declares;
+host-only handles expose the tables BodyFitter.__init__ of the reference would build."""
+
+import os.path as osp
+import re
+
+import numpy as np
+import pytest
+
+import util
+from smplfitter_amd import _lib, build
+
+ROOT = osp.dirname(osp.dirname(osp.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    build.build(verbose=False)
+    return _lib.load()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(osp.join(ROOT, 'include', 'smplfit.h')).read()
+    declared = set(re.findall(r'\b(smplfit_[a-z0-9_]+)\s*\(', hdr))
+    assert declared == set(_lib.EXPORTED_SYMBOLS)
+    for s in declared:
+        assert getattr(lib, s) is not None
+
+
+def test_no_device_fails_loudly(lib, model_root):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    kind, md = util.load_md(model_root, 'smpl')
+    import hostemu_util as H
+
+    desc, keep = H.desc_from_md(md, kind)
+    with pytest.raises(_lib.SmplfitError):
+        _lib.Handle(desc)  # uploading without a device must raise, never fall back
+    from smplfitter_amd.pt import BodyModel
+
+    m = BodyModel('smpl', 'neutral', model_root=f'{model_root}/smpl', num_betas=10)
+    with pytest.raises(RuntimeError):
+        m(pose_rotvecs=torch.zeros(1, 72))
+
+
+@pytest.mark.parametrize('name', ['smpl', 'smplx', 'smpl1024'])
+def test_host_tables_match_reference_structure(lib, name, model_root, golden):
+    g = golden(name)
+    kind, md = util.load_md(model_root, name, g)
+    import hostemu_util as H
+
+    desc, keep = H.desc_from_md(md, kind)
+    h = _lib.Handle(desc, host_only=True)
+    om, of = util.make_oracle(md, kind)
+    assert (h.table('part_assignment') == of.part).all()
+    ptype = h.table('part_type')
+    assert sorted(np.where(ptype == 1)[0]) == of.multi
+    assert sorted(np.where(ptype == 2)[0]) == of.bone
+    assert sorted(np.where(ptype == 3)[0]) == of.leaf
+    assert sorted(np.where(h.table('adj_flag') == 1)[0]) == sorted(of.adjustable)
+    assert sorted(np.where(h.table('used_part') == 1)[0]) == of.used_parts
+    starts = h.table('fk_level_start')
+    order = h.table('fk_order')
+    levels = [sorted(order[starts[i]:starts[i + 1]].tolist()) for i in range(len(starts) - 1)]
+    assert levels == [sorted(lv) for lv in of.levels]
+    if name == 'smpl':  # structural facts of SURVEY.md §8a
+        assert of.multi == [0, 9] and of.leaf == [15, 22, 23] and len(of.bone) == 17
+        assert [len(lv) for lv in levels] == [3, 3, 3, 5, 3, 2, 2, 2]
+    if name == 'smplx':
+        assert of.multi == [0, 9, 15, 20, 21] and len(of.bone) == 35 and len(of.leaf) == 13
+    perm = h.table('sort_perm')
+    V = md.num_vertices
+    assert sorted(perm[perm >= 0].tolist()) == list(range(V))
+    seg = h.table('segments').reshape(-1, 3)
+    used = np.isin(of.part, of.used_parts)
+    assert h.info.num_used_vertices == used.sum() == seg[:, 1].sum()
+    for s, c, p in seg:  # every segment is one part, at most one wave wide
+        assert 0 < c <= 64 and (of.part[perm[s:s + c]] == p).all()
+    assert h.info.skin_width == 4 and h.info.padded_vertices % 128 == 0
+    assert h.workspace_bytes(64) > 0
+    h.close()
+
+
+def test_create_rejects_bad_models(lib, model_root):
+    kind, md = util.load_md(model_root, 'smpl')
+    import hostemu_util as H
+
+    desc, keep = H.desc_from_md(md, kind)
+    desc.num_joints = 100
+    with pytest.raises(NotImplementedError):
+        _lib.Handle(desc, host_only=True)
+    desc, keep = H.desc_from_md(md, kind)
+    desc.v_template = None
+    with pytest.raises(ValueError):
+        _lib.Handle(desc, host_only=True)

@@ -1,0 +1,80 @@
+"""The kernels' arithmetic, compiled for the host (tests/hostemu): table builder, stage logic and the
+kernel orchestration checked against the golden vectors and the oracle — no GPU involved.
+This is a test harness of shared headers, not a product path."""
+
+import numpy as np
+import pytest
+
+import hostemu_util as H
+import util
+
+
+def test_primitives(golden):
+    lib = H.load()
+    g = golden('primitives')
+    n = int(g['proj_n_random'])
+    A = np.ascontiguousarray(g['proj_in'])
+    R = np.zeros_like(A)
+    lib.hostemu_proj_so3(H._p(A), H._p(R), len(A))
+    assert np.abs(R[:n] - g['proj_out'][:n]).max() < 2e-5
+    det = np.linalg.det(R.astype(np.float64))
+    assert np.abs(det - 1).max() < 1e-5
+    assert np.abs(R @ np.swapaxes(R, -1, -2) - np.eye(3)).max() < 1e-5
+    for i in (n + 2, n + 3, n + 5, n + 6, n + 7, n + 8):
+        assert np.abs(R[i] - g['proj_out'][i]).max() < 1e-4, i
+    assert np.abs(R[n + 4] - np.eye(3)).max() == 0  # zero matrix -> identity
+    rv = np.ascontiguousarray(g['rotvec_in'])
+    M = np.zeros((len(rv), 3, 3), np.float32)
+    lib.hostemu_rotvec2mat(H._p(rv), H._p(M), len(rv))
+    assert np.abs(M - g['rotvec2mat_out']).max() < 1e-6
+    Rin = np.ascontiguousarray(g['rotvec2mat_out'])
+    out = np.zeros((len(Rin), 3), np.float32)
+    lib.hostemu_mat2rotvec(H._p(Rin), H._p(out), len(Rin))
+    assert np.abs(out - g['mat2rotvec_out']).max() < 1e-5
+    a, b = np.ascontiguousarray(g['align_a']), np.ascontiguousarray(g['align_b'])
+    Ra = np.zeros((len(a), 3, 3), np.float32)
+    lib.hostemu_align(H._p(a), H._p(b), H._p(Ra), len(a))
+    assert np.abs(Ra[:-4] - g['align_out'][:-4]).max() < 1e-6
+    assert np.abs(Ra[-4:] - np.eye(3)).max() == 0  # exactly antiparallel: zero rotvec -> identity
+
+
+@pytest.mark.parametrize('name', ['smpl', 'smplx', 'smpl1024'])
+def test_forward(name, model_root, golden):
+    g = golden(name)
+    kind, md = util.load_md(model_root, name, g)
+    fw = H.forward(md, kind, g['pose'], g['betas'], g['trans'])
+    assert np.abs(fw['vertices'] - g['target_vertices']).max() < 2e-6
+    assert np.abs(fw['joints'] - g['fwd_joints']).max() < 2e-6
+    assert np.abs(fw['orientations'] - g['fwd_orientations']).max() < 1e-6
+    # global-rotation input reproduces the same mesh
+    fw2 = H.forward(md, kind, None, g['betas'], g['trans'], glob=g['fwd_orientations'])
+    assert np.abs(fw2['vertices'] - g['target_vertices']).max() < 5e-6
+
+
+@pytest.mark.parametrize('name', ['smpl', 'smplx', 'smpl1024'])
+def test_fit_goldens(name, model_root, golden):
+    g = golden(name)
+    kind, md = util.load_md(model_root, name, g)
+    om64, of64 = util.make_oracle(md, kind, np.float64)
+    pose_tol = 5e-3 if name == 'smplx' else 1.5e-3
+    G0 = None
+    for c in util.fit_configs(g):
+        cfg = util.cfg_from_name(c)
+        if not cfg['joints'] and name == 'smpl1024':
+            continue
+        o = H.fit(
+            md, kind, g['target_vertices'], g['target_joints'] if cfg['joints'] else None,
+            g['vertex_weights'] if cfg['weights'] else None,
+            g['joint_weights'] if (cfg['weights'] and cfg['joints']) else None,
+            num_iter=cfg['num_iter'], beta_regularizer=cfg['beta_regularizer'],
+            final_adjust_rots=cfg['final_adjust_rots'],
+        )
+        ref = {k: g[f'fit.{c}.{k}'] for k in ('pose_rotvecs', 'shape_betas', 'trans', 'orientations')}
+        assert util.vertex_l2(om64, o, ref) < 1e-4, c
+        assert np.abs(o['shape_betas'] - ref['shape_betas']).max() < 3e-4, c
+        assert np.abs(o['trans'] - ref['trans']).max() < 1e-5, c
+        assert np.abs(o['pose_rotvecs'] - ref['pose_rotvecs']).max() < pose_tol, c
+        assert np.abs(o['orientations'] - ref['orientations']).max() < pose_tol, c
+        if cfg['joints'] and not cfg['weights']:
+            G0 = o['glob_rotmats_iter0']
+    assert np.abs(G0 - g['stage.glob_rotmats_iter0']).max() < (2e-3 if name == 'smplx' else 5e-4)
