@@ -99,14 +99,16 @@ size_t smplfit_workspace_bytes(const smplfit_handle* h, int batch);
  * no warm start.
  *   target_vertices (B,V,3); target_joints (B,J,3) or NULL; vertex_weights (B,V) or NULL;
  *   joint_weights (B,J) or NULL.
- * Outputs: pose_rotvecs (B,3J), shape_betas (B,S), trans (B,3); orientations (B,J,3,3) may be NULL.
+ * Outputs: pose_rotvecs (B,3J), shape_betas (B,S), trans (B,3); orientations (B,J,3,3) and
+ * relative_orientations (B,J,3,3) (parent^T @ global, pt/bodyfitter.py:523-533) may be NULL.
  */
 int smplfit_fit_f32(const smplfit_handle* h, const float* target_vertices,
                     const float* target_joints, const float* vertex_weights,
                     const float* joint_weights, int batch, int num_iter, float beta_regularizer,
                     float beta_regularizer2, int final_adjust_rots, float* pose_rotvecs,
-                    float* shape_betas, float* trans, float* orientations, void* workspace,
-                    size_t workspace_bytes, void* hip_stream);
+                    float* shape_betas, float* trans, float* orientations,
+                    float* relative_orientations, void* workspace, size_t workspace_bytes,
+                    void* hip_stream);
 
 /*
  * BodyModel.forward (pt/bodymodel.py:121-307).  Exactly one of pose_rotvecs (B,3J) /

@@ -85,6 +85,11 @@ def load():
             f'{LIB_PATH} is missing: build it with `python -m smplfitter_amd.build` '
             '(hipcc, gfx950).  smplfitter_amd has no CPU fallback.'
         )
+    # PyTorch is the container for device memory and streams, so the kernels must run on the SAME
+    # HIP runtime instance torch uses: torch bundles a libamdhip64.so.7 with the same SONAME as the
+    # system one, and whichever is loaded first serves both.  Import torch first.
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     vp, sz, i32, f32 = C.c_void_p, C.c_size_t, C.c_int, C.c_float
     lib.smplfit_create.argtypes = [C.POINTER(ModelDesc), i32, C.POINTER(vp)]
@@ -99,7 +104,7 @@ def load():
     lib.smplfit_get_table.restype = i32
     lib.smplfit_workspace_bytes.argtypes = [vp, i32]
     lib.smplfit_workspace_bytes.restype = sz
-    lib.smplfit_fit_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, sz, vp]
+    lib.smplfit_fit_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.smplfit_fit_f32.restype = i32
     lib.smplfit_forward_f32.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, sz, vp]
     lib.smplfit_forward_f32.restype = i32

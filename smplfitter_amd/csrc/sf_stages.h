@@ -368,7 +368,7 @@ SF_HD void refine_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, co
                         const float* tj_in, const float* rj_joint_term, const float* rj_true,
                         const float* jw, const float* Gprev, const float* beta, const float* trans,
                         const float* mean, bool final_adjust, float* pose_out, float* beta_out,
-                        float* trans_out, float* orient_out) {
+                        float* trans_out, float* orient_out, float* rel_out) {
   const int J = tb.J, S = tb.S, S1 = S + 1;
   SF_FOR(k, J * 9) {
     sh.G[k] = Gprev[k];
@@ -443,6 +443,8 @@ SF_HD void refine_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, co
     for (int c = 0; c < 3; ++c) pose_out[j * 3 + c] = rv[c];
     if (orient_out)
       for (int k = 0; k < 9; ++k) orient_out[j * 9 + k] = sh.R[j * 9 + k];
+    if (rel_out)
+      for (int k = 0; k < 9; ++k) rel_out[j * 9 + k] = rel[k];
   }
   SF_FOR(i, S) beta_out[i] = beta[i];
   SF_FOR(c, 3) trans_out[c] = trans[c] + mean[c];  // (:519)

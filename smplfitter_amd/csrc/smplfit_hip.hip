@@ -558,7 +558,7 @@ struct RefineArgs {
   const float* rj_term;   // (B,J,3) reference joints of the joint term
   const float* jw;        // (B,J) or null
   int final_adjust;
-  float *pose, *betas, *trans, *orient;
+  float *pose, *betas, *trans, *orient, *rel;
 };
 
 __global__ __launch_bounds__(64) void k_refine_epilogue(DevModel m, RefineArgs a, Workspace ws) {
@@ -571,7 +571,8 @@ __global__ __launch_bounds__(64) void k_refine_epilogue(DevModel m, RefineArgs a
                    a.jw ? a.jw + (size_t)b * J : nullptr, ws.G + (size_t)b * J * 9,
                    ws.beta + (size_t)b * S, ws.trans + (size_t)b * 3, ws.mean + (size_t)b * 3,
                    a.final_adjust != 0, a.pose + (size_t)b * J * 3, a.betas + (size_t)b * S,
-                   a.trans + (size_t)b * 3, a.orient ? a.orient + (size_t)b * J * 9 : nullptr);
+                   a.trans + (size_t)b * 3, a.orient ? a.orient + (size_t)b * J * 9 : nullptr,
+                   a.rel ? a.rel + (size_t)b * J * 9 : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -679,7 +680,7 @@ struct FitOptions {
 
 int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const float* vw,
             const float* jw, int B, const FitOptions& o, float* pose, float* betas, float* trans,
-            float* orient, const Workspace& ws, hipStream_t st) {
+            float* orient, float* rel, const Workspace& ws, hipStream_t st) {
   const DevModel& d = h->d;
   const bool joints = tj != nullptr;
   if (!joints && !h->t.has_regressor)
@@ -755,6 +756,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   ra.betas = betas;
   ra.trans = trans;
   ra.orient = orient;
+  ra.rel = rel;
   hipLaunchKernelGGL(k_refine_epilogue, dim3(B), dim3(64), joint_lds(d), st, d, ra, ws);
   return post_launch_check();
 }
@@ -910,8 +912,9 @@ int smplfit_fit_f32(const smplfit_handle* h, const float* target_vertices,
                     const float* target_joints, const float* vertex_weights,
                     const float* joint_weights, int batch, int num_iter, float beta_regularizer,
                     float beta_regularizer2, int final_adjust_rots, float* pose_rotvecs,
-                    float* shape_betas, float* trans, float* orientations, void* workspace,
-                    size_t workspace_bytes, void* hip_stream) {
+                    float* shape_betas, float* trans, float* orientations,
+                    float* relative_orientations, void* workspace, size_t workspace_bytes,
+                    void* hip_stream) {
   int rc = check_common(h, batch, workspace, workspace_bytes);
   if (rc) return rc;
   if (!target_vertices || !pose_rotvecs || !shape_betas || !trans)
@@ -921,7 +924,8 @@ int smplfit_fit_f32(const smplfit_handle* h, const float* target_vertices,
   carve(h->t, batch, (char*)workspace, &ws);
   FitOptions o{num_iter, beta_regularizer, beta_regularizer2, final_adjust_rots ? 1 : 0, 0};
   return run_fit(h, target_vertices, target_joints, vertex_weights, joint_weights, batch, o,
-                 pose_rotvecs, shape_betas, trans, orientations, ws, (hipStream_t)hip_stream);
+                 pose_rotvecs, shape_betas, trans, orientations, relative_orientations, ws,
+                 (hipStream_t)hip_stream);
 }
 
 int smplfit_part_rotations_f32(const smplfit_handle* h, const float* target_vertices,
@@ -936,7 +940,7 @@ int smplfit_part_rotations_f32(const smplfit_handle* h, const float* target_vert
   carve(h->t, batch, (char*)workspace, &ws);
   FitOptions o{1, 0.f, 0.f, 0, 1};
   return run_fit(h, target_vertices, target_joints, vertex_weights, joint_weights, batch, o, nullptr,
-                 nullptr, nullptr, glob_rotmats, ws, (hipStream_t)hip_stream);
+                 nullptr, nullptr, glob_rotmats, nullptr, ws, (hipStream_t)hip_stream);
 }
 
 int smplfit_forward_f32(const smplfit_handle* h, const float* pose_rotvecs,

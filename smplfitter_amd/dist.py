@@ -1,0 +1,67 @@
+"""Batch sharding of the fit across the GPUs of one node (one process per GPU).
+
+The fit of every instance is independent (reference: all reductions in ``BodyFitter.fit`` are
+intra-instance unless ``share_beta``), so rank ``r`` of ``W`` fits a contiguous block of rows and the
+only communication is ONE all-gather of the packed result rows ``(B_local, 3J+S+3)`` —
+``torch.distributed`` backend ``nccl`` (= RCCL over xGMI) on GPUs, ``gloo`` in the CPU tests.
+"""
+
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous block ``[lo, hi)`` of ``total`` rows for ``rank``; sizes differ by at most one."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_results(res: dict) -> torch.Tensor:
+    """(B, 3J+S+3) rows: pose_rotvecs | shape_betas | trans."""
+    return torch.cat([res['pose_rotvecs'], res['shape_betas'], res['trans']], dim=1).contiguous()
+
+
+def unpack_results(rows: torch.Tensor, num_joints: int, num_betas: int) -> dict:
+    j3 = 3 * num_joints
+    return dict(
+        pose_rotvecs=rows[:, :j3], shape_betas=rows[:, j3:j3 + num_betas],
+        trans=rows[:, j3 + num_betas:j3 + num_betas + 3],
+    )
+
+
+def gather_rows(local_rows: torch.Tensor, total: int, group=None) -> torch.Tensor:
+    """All-gather ragged row blocks laid out by ``shard_range`` into one ``(total, C)`` tensor."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    sizes = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
+    assert local_rows.shape[0] == sizes[rank]
+    cols = local_rows.shape[1]
+    if len(set(sizes)) == 1:  # even shards: one fused collective
+        out = torch.empty((total, cols), dtype=local_rows.dtype, device=local_rows.device)
+        dist.all_gather_into_tensor(out, local_rows.contiguous(), group=group)
+        return out
+    mx = max(sizes)
+    padded = torch.zeros((mx, cols), dtype=local_rows.dtype, device=local_rows.device)
+    padded[: sizes[rank]] = local_rows
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    return torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)
+
+
+def fit_sharded(fit_fn, target_vertices: torch.Tensor, target_joints: Optional[torch.Tensor],
+                num_joints: int, num_betas: int, group=None, **fit_kwargs) -> dict:
+    """Every rank holds the FULL ``(B, V, 3)`` inputs (or generates them); each fits its block with
+    ``fit_fn`` (e.g. ``BodyFitter.fit``) and all ranks receive the full result dict."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    total = target_vertices.shape[0]
+    lo, hi = shard_range(total, rank, world)
+    res = fit_fn(target_vertices[lo:hi], None if target_joints is None else target_joints[lo:hi],
+                 **fit_kwargs)
+    rows = gather_rows(pack_results(res), total, group)
+    return unpack_results(rows, num_joints, num_betas)

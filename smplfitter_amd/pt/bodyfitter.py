@@ -100,6 +100,7 @@ class BodyFitter(nn.Module):
         betas = torch.empty((B, S), dtype=torch.float32, device=device)
         trans = torch.empty((B, 3), dtype=torch.float32, device=device)
         orient = torch.empty((B, J, 3, 3), dtype=torch.float32, device=device)
+        rel = torch.empty((B, J, 3, 3), dtype=torch.float32, device=device)
         if B > 0:
             h = bm._native(device)
             ws = _workspace if _workspace is not None else bm._workspace(h, B, device)
@@ -108,16 +109,12 @@ class BodyFitter(nn.Module):
                 _lib.check(_lib.load().smplfit_fit_f32(
                     h.ptr, _ptr(tv), _ptr(tj), _ptr(vw), _ptr(jw), B, int(num_iter),
                     float(beta_regularizer), float(beta_regularizer2), int(bool(final_adjust_rots)),
-                    _ptr(pose), _ptr(betas), _ptr(trans), _ptr(orient), _ptr(ws), ws.numel(),
-                    C.c_void_p(stream)))
-        result = dict(shape_betas=betas, trans=trans, orientations=orient)
-        # relative orientations = parent^T @ global (pt/bodyfitter.py:523-533); returned always
-        # (the reference returns the pre-refinement ones when neither rotation key is requested)
-        parents = bm.kintree_parents_tensor[1:].to(device)
-        parent_glob = torch.cat(
-            [torch.eye(3, device=device).expand(B, 1, 3, 3), orient.index_select(1, parents)], dim=1
-        )
-        result['relative_orientations'] = parent_glob.transpose(-1, -2) @ orient
+                    _ptr(pose), _ptr(betas), _ptr(trans), _ptr(orient), _ptr(rel), _ptr(ws),
+                    ws.numel(), C.c_void_p(stream)))
+        # relative_orientations = parent^T @ global of the FINAL rotations (pt/bodyfitter.py:523-533);
+        # returned always (the reference returns the pre-refinement ones when neither
+        # 'relative_orientations' nor 'pose_rotvecs' is requested)
+        result = dict(shape_betas=betas, trans=trans, orientations=orient, relative_orientations=rel)
         if 'pose_rotvecs' in requested_keys:
             result['pose_rotvecs'] = pose
         return result

@@ -255,7 +255,7 @@ int fit_impl(const sf::HostTables& t, const float* tv, const float* tj, const fl
                      e.G.data() + (size_t)b * t.J * 9, e.beta.data() + (size_t)b * S,
                      e.trans.data() + (size_t)b * 3, e.mean.data() + (size_t)b * 3, final_adjust != 0,
                      pose + (size_t)b * t.J * 3, betas + (size_t)b * S, trans + (size_t)b * 3,
-                     orient ? orient + (size_t)b * t.J * 9 : nullptr);
+                     orient ? orient + (size_t)b * t.J * 9 : nullptr, nullptr);
   return 0;
 }
 
