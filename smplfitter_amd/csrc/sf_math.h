@@ -10,6 +10,14 @@
 #define SF_HD inline
 #endif
 
+// Scheduling fence for the device compiler: stops it from hoisting the LDS loads of later phases
+// above earlier ones (which explodes register pressure in the per-vertex bodies). No-op on host.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SF_SCHED_FENCE() ((void)0)
+#endif
+
 namespace sf {
 
 // a / b, 0 where b == 0 (rotation.py:8-11)

@@ -26,6 +26,12 @@ SF_HD constexpr int ne_ng(int S) { return S * (S + 1) / 2; }
 SF_HD constexpr int ne_size(int S) { return ne_ng(S) + S + 3 * S + 3; }  // W sits at [ne_size]
 SF_HD constexpr int ne_g(int S, int i, int j) { return i * S - i * (i - 1) / 2 + (j - i); }
 
+// floats per vertex of the packed constants record (must match HostTables::cstride())
+SF_HD constexpr int cpack_stride(int S, int KW) {
+  return ((3 * S + KW + KW / 4 + 3) / 4 * 4) % 8 == 4 ? (3 * S + KW + KW / 4 + 3) / 4 * 4
+                                                      : (3 * S + KW + KW / 4 + 3) / 4 * 4 + 4;
+}
+
 constexpr int kPsum = 16;  // part-sum record: raw 9, s_t 3, s_a 3, s_w 1
 
 struct alignas(16) F4 {
@@ -39,6 +45,8 @@ struct JointTabs {
   const int32_t *parents, *fk_js, *fk_level_start, *cas_start, *cas_flat, *part_type, *toe_src;
   const int32_t *adj_level_start, *adj_parts;
   const float *j_ext, *bone_ext;  // (J,3,S+1)
+  const float *cs_joint;  // (J,3,S) sum_v w_vj shapedirs_v   (closed-form vertex-block SA)
+  const float *cw_joint;  // (J)     sum_v w_vj
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -91,7 +99,7 @@ template <class Ctx>
 SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, const float* psum,
                        const float* tjc, const float* rj_in, const float* Gprev, const float* jw,
                        bool fit_rotations, bool do_prologue, bool joint_block,
-                       bool joint_block_weighted, float* Gout,
+                       bool joint_block_weighted, bool vertex_sa_closed_form, float* Gout,
                        float* rp_out, float* jd_out, float* pext_out, float* gramj_out) {
   const int J = tb.J, S = tb.S, S1 = S + 1;
   SF_FOR(k, J * 3) {
@@ -210,6 +218,7 @@ SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
     for (int c = 0; c < 3; ++c) {
       const float p = sh.P[(j * 3 + c) * S1 + s];
       const float tv = p - (Gj[c * 3] * e0 + Gj[c * 3 + 1] * e1 + Gj[c * 3 + 2] * e2);
+      sh.T[(j * 3 + c) * S1 + s] = tv;
       pext_out[(j * 3 + c) * S1 + s] = p;
       if (s == 0)
         jd_out[j * stride + 9 + c] = tv;
@@ -224,8 +233,19 @@ SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
   }
   // joint block of the normal equations, fp32 sums (:1051-1053, _gram_block :1598-1625)
   const int NG = ne_ng(S), NE = ne_size(S);
+  cx.sync();
   SF_FOR(e, NE + 1) {
     float acc = 0.f;
+    if (vertex_sa_closed_form && e >= NG + S && e < NG + 4 * S) {
+      // vertex-block SA with unit weights, sum_v Jac_v[c][i] = sum_j (G_j CS_j)[c][i] + cw_j T'_j[c][i]
+      const int c = (e - NG - S) / S, i = (e - NG - S) % S;
+      for (int j = 0; j < J; ++j) {
+        const float* Gj = sh.G + j * 9 + c * 3;
+        const float* cs = tb.cs_joint + j * 3 * S + i;
+        acc += (Gj[0] * cs[0] + Gj[1] * cs[S] + Gj[2] * cs[2 * S]) +
+               tb.cw_joint[j] * sh.T[(j * 3 + c) * S1 + 1 + i];
+      }
+    }
     if (joint_block) {
       if (e < NG) {
         int i = 0, r = e;
@@ -539,6 +559,8 @@ SF_HD void forward_joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch&
 
 // ---------------------------------------------------------------------------------------------
 // Per-vertex bodies (lane = vertex).  jd = the instance's joint block (LDS on the GPU).
+// rec = the vertex's packed constants record (HostTables::cpackA/B, LDS on the GPU), cpack_stride
+// floats: [shapedirs s-major: rec[s*3 + a], 3S floats][KW weights][KW/4 words of 4 joint ids].
 // ---------------------------------------------------------------------------------------------
 template <int KW>
 struct Skin {
@@ -546,21 +568,23 @@ struct Skin {
   float w[KW];
 };
 
-template <int KW>
-SF_HD Skin<KW> load_skin(const uint32_t* widx, const float* wval, int Vp, int i) {
+template <int S, int KW>
+SF_HD Skin<KW> skin_from_rec(const float* rec) {
   Skin<KW> s;
 #pragma unroll
+  for (int k = 0; k < KW; ++k) s.w[k] = rec[3 * S + k];
+#pragma unroll
   for (int q = 0; q < KW / 4; ++q) {
-    const uint32_t u = widx[(size_t)q * Vp + i];
+    uint32_t u;
+    const float f = rec[3 * S + KW + q];
+    __builtin_memcpy(&u, &f, 4);
 #pragma unroll
     for (int k = 0; k < 4; ++k) s.j[q * 4 + k] = (int)((u >> (8 * k)) & 0xffu);
   }
-#pragma unroll
-  for (int k = 0; k < KW; ++k) s.w[k] = wval[(size_t)k * Vp + i];
   return s;
 }
 
-// blended rotation and (optionally) translation from 3 F4 per joint: R0..R8, T0
+// blended rotation and translation from 3 F4 per joint: R0..R8, T0
 template <int S, int KW>
 SF_HD void blend_rt(const float* jd, const Skin<KW>& sk, float* Rt, float* T0) {
   constexpr int STRIDE = jd_stride(S);
@@ -581,26 +605,47 @@ SF_HD void blend_rt(const float* jd, const Skin<KW>& sk, float* Rt, float* T0) {
 // Normal-equation accumulation of one vertex (_fit_shape_gram, bodyfitter.py:999-1048):
 //   Rt = sum_j w_j G_j;  pos = Rt v_posed + sum_j w_j T0_j;  b = t - pos
 //   Jac[c][s] = Rt[c][:] . shapedirs[:, s] + sum_j w_j T'_j[c][s]
-//   G += w Jac^T Jac, r += w Jac^T b, SA[c] += w Jac[c], Sb[c] += w b[c]
-// sdv: the vertex's shapedirs, [c'*S + s].  acc: NE floats (W is handled by the caller).
+//   G += w Jac^T Jac, r += w Jac^T b, Sb[c] += w b[c]; SA[c] += w Jac[c] only when WEIGHTED — with
+//   unit weights SA = sum_v Jac_v is target-independent and the joint stage evaluates it in closed
+//   form from per-joint constants (JointTabs::cs_joint / cw_joint).
+// acc: NE floats in the NE layout (W is handled by the caller).
 template <int S, int KW, bool WEIGHTED>
-SF_HD void shape_accum_vertex(const float* jd, const Skin<KW>& sk, const float* vp,
-                              const float* tv, const float* sdv, float wv, float* acc) {
-  constexpr int STRIDE = jd_stride(S), ROW = jd_row(S), NG = ne_ng(S);
-  float Rt[9], T0[3];
-  blend_rt<S, KW>(jd, sk, Rt, T0);
-  float b[3];
+SF_HD void shape_accum_vertex(const float* jd, const float* rec, const float* vp, const float* tv,
+                              float wv, float* priv, float* acc) {
+  constexpr int STRIDE = jd_stride(S), ROW = jd_row(S), NG = ne_ng(S), SD = 3 * S;
+  const Skin<KW> sk = skin_from_rec<S, KW>(rec);
+  {
+    float Rt[9], T0[3];
+    blend_rt<S, KW>(jd, sk, Rt, T0);
+    // blended rotation row + residual of each coordinate go to a lane-private 12-float slot
+    // (LDS on the GPU) so that the loop over the 3 coordinates below can stay ROLLED: fully unrolled
+    // the compiler hoists every LDS load of all three rows (~190 live registers) and spills.
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const float pos = (Rt[c * 3] * vp[0] + Rt[c * 3 + 1] * vp[1] + Rt[c * 3 + 2] * vp[2]) + T0[c];
-    b[c] = tv[c] - pos;
+    for (int c = 0; c < 3; ++c) {
+      const float pos = (Rt[c * 3] * vp[0] + Rt[c * 3 + 1] * vp[1] + Rt[c * 3 + 2] * vp[2]) + T0[c];
+      const float bc = tv[c] - pos;
+      priv[c * 4] = Rt[c * 3];
+      priv[c * 4 + 1] = Rt[c * 3 + 1];
+      priv[c * 4 + 2] = Rt[c * 3 + 2];
+      priv[c * 4 + 3] = bc;
+      acc[NG + 4 * S + c] += WEIGHTED ? wv * bc : bc;
+    }
   }
+  float sd[SD + 3];  // shapedirs of the vertex, s-major: sd[s*3 + a]
 #pragma unroll
+  for (int q = 0; q < (SD + 3) / 4; ++q) {
+    const F4 t = ld4(rec + 4 * q);
+    if (4 * q < SD) sd[4 * q] = t.x;
+    if (4 * q + 1 < SD) sd[4 * q + 1] = t.y;
+    if (4 * q + 2 < SD) sd[4 * q + 2] = t.z;
+    if (4 * q + 3 < SD) sd[4 * q + 3] = t.w;
+  }
+#pragma unroll 1
   for (int c = 0; c < 3; ++c) {
+    const F4 rb = ld4(priv + c * 4);
     float a[ROW];
 #pragma unroll
-    for (int s = 0; s < S; ++s)
-      a[s] = Rt[c * 3] * sdv[s] + Rt[c * 3 + 1] * sdv[S + s] + Rt[c * 3 + 2] * sdv[2 * S + s];
+    for (int s = 0; s < S; ++s) a[s] = rb.x * sd[s * 3] + rb.y * sd[s * 3 + 1] + rb.z * sd[s * 3 + 2];
 #pragma unroll
     for (int s = S; s < ROW; ++s) a[s] = 0.f;
 #pragma unroll
@@ -613,27 +658,30 @@ SF_HD void shape_accum_vertex(const float* jd, const Skin<KW>& sk, const float* 
         a[4 * q] += w * t.x; a[4 * q + 1] += w * t.y; a[4 * q + 2] += w * t.z; a[4 * q + 3] += w * t.w;
       }
     }
-    const float bc = WEIGHTED ? wv * b[c] : b[c];
+    const float bc = rb.w;
 #pragma unroll
     for (int i = 0; i < S; ++i) {
       const float wa = WEIGHTED ? wv * a[i] : a[i];
 #pragma unroll
       for (int j = i; j < S; ++j) acc[ne_g(S, i, j)] += wa * a[j];
-      acc[NG + i] += wa * b[c];
-      acc[NG + S + c * S + i] += wa;
+      acc[NG + i] += wa * bc;
+      if (WEIGHTED) {  // SA[c][i]: the only c-indexed accumulators; branches keep the indices static
+        if (c == 0) acc[NG + S + i] += wa;
+        else if (c == 1) acc[NG + 2 * S + i] += wa;
+        else acc[NG + 3 * S + i] += wa;
+      }
     }
-    acc[NG + 4 * S + c] += bc;
   }
 }
 
 // Vertex at the solved shape (bodyfitter.py:1099-1101; LBS of bodymodel.py:288-306):
-//   v = Rt (v_posed + shapedirs beta) + sum_j w_j jb_j (+ trans)
-// jb: (J,4) per-joint skinning translation at the solution.
+//   v = Rt (v_posed + shapedirs beta) + sum_j w_j jb_j + trans
+// jb: (J,4) per-joint skinning translation at the solution; beta: S values (zero beyond nb).
 template <int S, int KW>
-SF_HD void lbs_vertex(const float* jd, const float* jb, const Skin<KW>& sk, const float* vp,
-                      const float* sdv, const float* beta, int nb, const float* trans,
-                      float* out) {
-  constexpr int STRIDE = jd_stride(S);
+SF_HD void lbs_vertex(const float* jd, const float* jb, const float* rec, const float* vp,
+                      const float* beta, const float* trans, float* out) {
+  constexpr int STRIDE = jd_stride(S), SD = 3 * S;
+  const Skin<KW> sk = skin_from_rec<S, KW>(rec);
   float Rt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Tb[3] = {0, 0, 0};
 #pragma unroll
   for (int k = 0; k < KW; ++k) {
@@ -647,14 +695,16 @@ SF_HD void lbs_vertex(const float* jd, const float* jb, const Skin<KW>& sk, cons
     Rt[8] += w * r8;
     Tb[0] += w * t.x; Tb[1] += w * t.y; Tb[2] += w * t.z;
   }
-  float vs[3];
+  float vs[3] = {vp[0], vp[1], vp[2]};
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    float acc = 0.f;
+  for (int q = 0; q < (SD + 3) / 4; ++q) {
+    const F4 t = ld4(rec + 4 * q);
+    const float f[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-    for (int s = 0; s < S; ++s)
-      if (s < nb) acc += sdv[c * S + s] * beta[s];
-    vs[c] = vp[c] + acc;
+    for (int e = 0; e < 4; ++e) {
+      const int k = 4 * q + e;
+      if (k < SD) vs[k % 3] += f[e] * beta[k / 3];
+    }
   }
 #pragma unroll
   for (int c = 0; c < 3; ++c)

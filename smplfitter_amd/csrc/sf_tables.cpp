@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <numeric>
 
 namespace sf {
@@ -196,6 +197,24 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
     }
   }
   t.vtN = t.vt;
+  {
+    const int cs = t.cstride();
+    auto pack = [&](float* dst, int slot) {  // one vertex record
+      for (int c = 0; c < 3; ++c)
+        for (int s2 = 0; s2 < S; ++s2) dst[s2 * 3 + c] = t.sd[(size_t)(c * S + s2) * Vp + slot];
+      for (int k = 0; k < t.KW; ++k) dst[3 * S + k] = t.wval[(size_t)k * Vp + slot];
+      for (int q = 0; q < t.KW / 4; ++q) {
+        const uint32_t u = t.widx[(size_t)q * Vp + slot];
+        std::memcpy(dst + 3 * S + t.KW + q, &u, 4);
+      }
+    };
+    t.cpackA.assign((size_t)Vp * cs, 0.f);
+    for (int i = 0; i < Vp; ++i) pack(t.cpackA.data() + (size_t)i * cs, i);
+    t.cpackB.assign(t.segments.size() * 64 * cs, 0.f);
+    for (size_t sgi = 0; sgi < t.segments.size(); ++sgi)
+      for (int l = 0; l < t.segments[sgi].count; ++l)
+        pack(t.cpackB.data() + (sgi * 64 + l) * cs, t.segments[sgi].start + l);
+  }
 
   // ---- per-joint constants (:52-58, :191-192) ----
   const int S1 = S + 1;
@@ -223,6 +242,22 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
       t.sw0[p] += 1.f;
     }
     for (size_t k = 0; k < acc.size(); ++k) t.sa0[k] = (float)acc[k];
+  }
+
+  // closed-form SA constants: sum over ALL vertices (the Gramian runs over every vertex)
+  {
+    std::vector<double> cs((size_t)J * 3 * S, 0.0), cw(J, 0.0);
+    for (int v = 0; v < V; ++v)
+      for (int j = 0; j < J; ++j) {
+        const double w = d.weights[(size_t)v * J + j];
+        if (w == 0.0) continue;
+        cw[j] += w;
+        for (int k = 0; k < 3 * S; ++k) cs[(size_t)j * 3 * S + k] += w * d.shapedirs[(size_t)v * 3 * S + k];
+      }
+    t.cs_joint.assign(cs.size(), 0.f);
+    t.cw_joint.assign(J, 0.f);
+    for (size_t k = 0; k < cs.size(); ++k) t.cs_joint[k] = (float)cs[k];
+    for (int j = 0; j < J; ++j) t.cw_joint[j] = (float)cw[j];
   }
 
   // ---- sparse joint regressor over sorted slots ----

@@ -61,18 +61,30 @@ struct HostTables {
   std::vector<float> wval;      // (KW, Vp)
   std::vector<float> pdT;       // (Kp, 3*Vp) posedirs, K-major
   std::vector<float> vtN;       // (3*Vp) v_template in GEMM column order (== vt flattened)
+  // per-vertex constants packed per 64-vertex tile for cooperative staging through LDS:
+  // cstride() floats per vertex = [shapedirs s-major (s*3+c), 3*S | KW weights | KW/4 index words | pad]
+  std::vector<float> cpackA;    // (Vp/64, 64, cstride) dense tiles of sorted slots  (shape accumulate)
+  std::vector<float> cpackB;    // (nseg, 64, cstride)  part-aligned segments        (LBS + part sums)
 
   // per-joint constants
   std::vector<float> j_ext;     // (J,3,S+1)  [J_template | J_shapedirs]
   std::vector<float> bone_ext;  // (J,3,S+1)  j_ext - j_ext[parent] (root: j_ext - j_ext[0] = 0)
   std::vector<float> sa0;       // (J,3) sum of default-mesh vertices per part (template pass)
   std::vector<float> sw0;       // (J)   vertex count per part
+  std::vector<float> cs_joint;  // (J,3,S) sum_v w_vj shapedirs_v  (closed-form SA of the vertex block)
+  std::vector<float> cw_joint;  // (J)     sum_v w_vj
 
   // sparse post-LBS joint regressor, CSR over sorted slots (joints-omitted path)
   std::vector<int32_t> reg_start, reg_slot;
   std::vector<float> reg_val;
 
   int num_levels() const { return (int)fk_level_start.size() - 1; }
+  // floats per vertex in cpack: multiple of 4 (16-B rows) and = 4 (mod 8) so that 16 consecutive
+  // lanes reading 16 B at this stride hit distinct LDS banks
+  int cstride() const {
+    int n = (3 * S + KW + KW / 4 + 3) / 4 * 4;
+    return n % 8 == 4 ? n : n + 4;
+  }
   int ne() const { return S * (S + 1) / 2 + S + 3 * S + 3; }  // normal-equation entries (+1 for W)
 };
 

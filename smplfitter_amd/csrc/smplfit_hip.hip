@@ -50,7 +50,7 @@ struct DevModel {
   sf::JointTabs jt;
   const int32_t* perm;      // (Vp)
   const int32_t* segments;  // (nseg,3)
-  const float *vt, *dm, *sd, *wval, *pdT, *vtN, *j_template;
+  const float *vt, *dm, *sd, *wval, *pdT, *vtN, *j_template, *cpackA, *cpackB;
   const uint32_t* widx;
   const int32_t *reg_start, *reg_slot;
   const float* reg_val;
@@ -273,7 +273,7 @@ struct JointStageArgs {
   int rj_shared;
   const float* Gprev;    // (B,J,9) or null
   const float* jw;       // (B,J) or null
-  int fit_rotations, do_prologue, joint_block, joint_block_weighted;
+  int fit_rotations, do_prologue, joint_block, joint_block_weighted, vertex_sa_closed_form;
 };
 
 __global__ __launch_bounds__(64) void k_joint_stage(DevModel m, JointStageArgs a, Workspace ws) {
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(64) void k_joint_stage(DevModel m, JointStageArgs a
                   a.Gprev ? a.Gprev + (size_t)b * J * 9 : nullptr,
                   a.jw ? a.jw + (size_t)b * J : nullptr, a.fit_rotations != 0, a.do_prologue != 0,
                   a.joint_block != 0,
-                  a.joint_block_weighted != 0, ws.G + (size_t)b * J * 9,
+                  a.joint_block_weighted != 0, a.vertex_sa_closed_form != 0, ws.G + (size_t)b * J * 9,
                   ws.rp + (size_t)b * m.Kp, ws.jd + (size_t)b * J * sf::jd_stride(S),
                   ws.pext + (size_t)b * J * 3 * (S + 1), ws.gramj + (size_t)b * NE1);
 }
@@ -375,56 +375,108 @@ __global__ __launch_bounds__(256) void k_posedirs_gemm(const float* __restrict__
       }
 }
 
+// DPP wave-64 sum (6 VALU ops, no LDS traffic); the total lands in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_step(float v) {
+  const int x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  return v + __builtin_bit_cast(float, x);
+}
+__device__ __forceinline__ float wave_sum_last(float v) {
+  v = dpp_step<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_step<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_step<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_step<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of each row holds the row total
+  v = dpp_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1,3
+  v = dpp_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave total
+  return v;
+}
+
+constexpr int kNW = 4;  // instances (= waves) per workgroup in the vertex kernels
+
 // ------------------------------------------------------------------------------------------------
-// K3: vertex block of the normal equations.  grid B, block 256.
-// dynamic LDS: joint block (J*jd_stride floats) + 4 x (NE+1) wave partials.
+// K3: vertex block of the normal equations.  grid ceil(B/4), block 256: wave w fits instance
+// 4*blockIdx + w; the 4 waves walk the vertex tiles in lockstep so that the per-vertex constants
+// (shapedirs, skinning pairs: 144 B/vertex) are fetched ONCE per workgroup and staged through a
+// double-buffered LDS tile; per-instance streams (targets, v_posed) are register-prefetched one
+// tile ahead.  98 fp32 accumulators per lane, DPP wave reduction, fp64 result.
+// dynamic LDS: 4 joint blocks + 2 x (64 x cstride) constants.
 // ------------------------------------------------------------------------------------------------
 template <int S, int KW, bool WEIGHTED>
-__global__ __launch_bounds__(256) void k_shape_accum(DevModel m, Workspace ws) {
+__global__ __launch_bounds__(256, 2) void k_shape_accum(DevModel m, Workspace ws, int B) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NE = sf::ne_size(S), STRIDE = sf::jd_stride(S);
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int J = m.J, Vp = m.Vp;
-  float* jd = smem;
-  float* red = smem + J * STRIDE;  // [4][NE+1]
+  constexpr int CS = sf::cpack_stride(S, KW), TILE_F4 = 64 * CS / 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int J = m.J, Vp = m.Vp, ntiles = Vp / 64;
+  const int b_raw = blockIdx.x * kNW + wave;
+  const int b = b_raw < B ? b_raw : B - 1;
+  float* jd = smem + wave * J * STRIDE;
+  float* cst = smem + kNW * J * STRIDE;  // [2][64*CS]
+  float* priv = cst + 2 * 64 * CS + tid * 12;  // lane-private 12 floats (48-B stride: conflict-free b128)
   {
     const float4* src = reinterpret_cast<const float4*>(ws.jd + (size_t)b * J * STRIDE);
     float4* dst = reinterpret_cast<float4*>(jd);
-    for (int k = tid; k < J * STRIDE / 4; k += 256) dst[k] = src[k];
+    for (int k = lane; k < J * STRIDE / 4; k += 64) dst[k] = src[k];
   }
-  __syncthreads();
+  // cooperative staging of the constants tile: TILE_F4 float4 over 256 threads (<= 3 each), kept in
+  // named registers (an indexed array here ends up in scratch)
+  const float4* cg = reinterpret_cast<const float4*>(m.cpackA);
+  static_assert(TILE_F4 <= 1024, "constants tile too large for 4 float4 per thread");
+  float4 c0, c1, c2, c3;
+  auto cload = [&](int tile) {
+    const float4* src = cg + (size_t)tile * TILE_F4;
+    c0 = src[tid];
+    if (TILE_F4 > 256 && tid + 256 < TILE_F4) c1 = src[tid + 256];
+    if (TILE_F4 > 512 && tid + 512 < TILE_F4) c2 = src[tid + 512];
+    if (TILE_F4 > 768 && tid + 768 < TILE_F4) c3 = src[tid + 768];
+  };
+  auto cstore = [&](int buf) {
+    float4* dst = reinterpret_cast<float4*>(cst + buf * 64 * CS);
+    dst[tid] = c0;
+    if (TILE_F4 > 256 && tid + 256 < TILE_F4) dst[tid + 256] = c1;
+    if (TILE_F4 > 512 && tid + 512 < TILE_F4) dst[tid + 512] = c2;
+    if (TILE_F4 > 768 && tid + 768 < TILE_F4) dst[tid + 768] = c3;
+  };
   const float* tvs = ws.tvs + (size_t)b * 3 * Vp;
   const float* vps = ws.vposed + (size_t)b * 3 * Vp;
   const float* vws = ws.vws + (size_t)b * Vp;
+  float nx[7];
+  auto sload = [&](int tile) {
+    const int i = tile * 64 + lane;
+    nx[0] = vps[i]; nx[1] = vps[Vp + i]; nx[2] = vps[2 * Vp + i];
+    nx[3] = tvs[i]; nx[4] = tvs[Vp + i]; nx[5] = tvs[2 * Vp + i];
+    nx[6] = WEIGHTED ? vws[i] : 1.f;
+  };
+  cload(0);
+  sload(0);
+  cstore(0);
+  __syncthreads();
   float acc[NE + 1];
 #pragma unroll
   for (int k = 0; k <= NE; ++k) acc[k] = 0.f;
-  for (int tile = wave; tile < Vp / 64; tile += 4) {
-    const int i = tile * 64 + lane;
-    const sf::Skin<KW> sk = sf::load_skin<KW>(m.widx, m.wval, Vp, i);
-    const float vp[3] = {vps[i], vps[Vp + i], vps[2 * Vp + i]};
-    const float tv[3] = {tvs[i], tvs[Vp + i], tvs[2 * Vp + i]};
-    float sdv[3 * S];
-#pragma unroll
-    for (int k = 0; k < 3 * S; ++k) sdv[k] = m.sd[(size_t)k * Vp + i];
-    float wv = 1.f;
-    if (WEIGHTED) {
-      wv = vws[i];
-      acc[NE] += wv;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const float vp[3] = {nx[0], nx[1], nx[2]};
+    const float tv[3] = {nx[3], nx[4], nx[5]};
+    const float wv = nx[6];
+    if (tile + 1 < ntiles) {
+      cload(tile + 1);
+      sload(tile + 1);
     }
-    sf::shape_accum_vertex<S, KW, WEIGHTED>(jd, sk, vp, tv, sdv, wv, acc);
+    if (WEIGHTED) acc[NE] += wv;
+    sf::shape_accum_vertex<S, KW, WEIGHTED>(jd, cst + (tile & 1) * 64 * CS + lane * CS, vp, tv, wv,
+                                            priv, acc);
+    if (tile + 1 < ntiles) cstore((tile + 1) & 1);
+    __syncthreads();
   }
+  double* out = ws.gramv + (size_t)b * (NE + 1);
+  constexpr int NG = sf::ne_ng(S);
 #pragma unroll
   for (int k = 0; k <= NE; ++k) {
-    const float r = wave_sum(acc[k]);
-    if (lane == 0) red[wave * (NE + 1) + k] = r;
-  }
-  __syncthreads();
-  for (int k = tid; k <= NE; k += 256) {
-    double v = ((double)red[k] + (double)red[(NE + 1) + k]) +
-               ((double)red[2 * (NE + 1) + k] + (double)red[3 * (NE + 1) + k]);
-    if (!WEIGHTED && k == NE) v = (double)m.V;  // w_sum = num_vertices (bodyfitter.py:1038-1040)
-    ws.gramv[(size_t)b * (NE + 1) + k] = v;
+    // unit weights: SA comes from the joint stage in closed form, W = V (bodyfitter.py:1038-1040)
+    const bool dead = !WEIGHTED && ((k >= NG + S && k < NG + 4 * S) || k == NE);
+    float r = 0.f;
+    if (!dead) r = wave_sum_last(acc[k]);
+    if (lane == 63 && b_raw < B) out[k] = dead ? (k == NE ? (double)m.V : 0.0) : (double)r;
   }
 }
 
@@ -445,109 +497,166 @@ __global__ __launch_bounds__(64) void k_shape_solve(DevModel m, Workspace ws, fl
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5: vertices at the solved shape + part sums against the targets.  grid B, block 256.
+// K5: vertices at the solved shape + part sums against the targets.  grid ceil(B/4), block 256,
+// wave = instance, lockstep over the part-aligned segments with LDS-staged constants (as K3).
 // MODE 0: part sums only (joints given).  MODE 1: also store the vertices (sorted SoA) for the
 // joint regression of the joints-omitted path.  MODE 2: store vertices in ORIGINAL order to `out`
-// (B,V,3) (shape-solve entry point / forward) — no part sums.
-// dynamic LDS: joint block + jb (J*4) + 4 x J x 16 partials.
+// (B,V,3) (shape-solve entry point / forward) over ALL slots — no part sums.
+// dynamic LDS: 4 x (joint block rows R|T0 + jb) + 2 x (64 x cstride) constants + 4 x 36.
 // ------------------------------------------------------------------------------------------------
 template <int S, int KW, bool WEIGHTED, int MODE>
-__global__ __launch_bounds__(256) void k_lbs_partsum(DevModel m, Workspace ws, int nb,
+__global__ __launch_bounds__(256) void k_lbs_partsum(DevModel m, Workspace ws, int B, int nb,
                                                      const float* __restrict__ beta_in,
                                                      const float* __restrict__ trans_in,
                                                      float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int STRIDE = sf::jd_stride(S);
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int CS = sf::cpack_stride(S, KW), TILE_F4 = 64 * CS / 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int J = m.J, Vp = m.Vp, V = m.V;
-  float* jd = smem;
+  const int b_raw = blockIdx.x * kNW + wave;
+  const int b = b_raw < B ? b_raw : B - 1;
+  const bool live = b_raw < B;
+  float* jd = smem + wave * (J * STRIDE + J * 4 + 36);
   float* jb = jd + J * STRIDE;
-  float* pacc = jb + J * 4;
-  float* sbeta = pacc + 4 * J * sf::kPsum;  // [32]
-  float* strans = sbeta + 32;               // [4]
+  float* sbeta = jb + J * 4;   // [32]
+  float* strans = sbeta + 32;  // [4]
+  float* cst = smem + kNW * (J * STRIDE + J * 4 + 36);
   {
     const float4* src = reinterpret_cast<const float4*>(ws.jd + (size_t)b * J * STRIDE);
     float4* dst = reinterpret_cast<float4*>(jd);
-    for (int k = tid; k < J * STRIDE / 4; k += 256) dst[k] = src[k];
-    for (int k = tid; k < J * 4; k += 256) jb[k] = ws.jb[(size_t)b * J * 4 + k];
-    if (MODE != 2)
-      for (int k = tid; k < 4 * J * sf::kPsum; k += 256) pacc[k] = 0.f;
-    if (tid < S) sbeta[tid] = (beta_in && tid < nb) ? beta_in[(size_t)b * nb + tid] : 0.f;
-    if (tid < 3) strans[tid] = trans_in ? trans_in[(size_t)b * 3 + tid] : 0.f;
+    for (int k = lane; k < J * STRIDE / 4; k += 64) dst[k] = src[k];
+    for (int k = lane; k < J * 4; k += 64) jb[k] = ws.jb[(size_t)b * J * 4 + k];
+    if (lane < S) sbeta[lane] = (beta_in && lane < nb) ? beta_in[(size_t)b * nb + lane] : 0.f;
+    if (lane < 3) strans[lane] = trans_in ? trans_in[(size_t)b * 3 + lane] : 0.f;
   }
-  __syncthreads();
+  // MODE 2 walks the dense tiles (every slot), the other modes the part-aligned segments
+  const int nsteps = MODE == 2 ? Vp / 64 : m.nseg;
+  // cooperative staging of the constants tile: TILE_F4 float4 over 256 threads (<= 3 each), kept in
+  // named registers (an indexed array here ends up in scratch)
+  const float4* cg = reinterpret_cast<const float4*>(MODE == 2 ? m.cpackA : m.cpackB);
+  static_assert(TILE_F4 <= 1024, "constants tile too large for 4 float4 per thread");
+  float4 c0, c1, c2, c3;
+  auto cload = [&](int step) {
+    const float4* src = cg + (size_t)step * TILE_F4;
+    c0 = src[tid];
+    if (TILE_F4 > 256 && tid + 256 < TILE_F4) c1 = src[tid + 256];
+    if (TILE_F4 > 512 && tid + 512 < TILE_F4) c2 = src[tid + 512];
+    if (TILE_F4 > 768 && tid + 768 < TILE_F4) c3 = src[tid + 768];
+  };
+  auto cstore = [&](int buf) {
+    float4* dst = reinterpret_cast<float4*>(cst + buf * 64 * CS);
+    dst[tid] = c0;
+    if (TILE_F4 > 256 && tid + 256 < TILE_F4) dst[tid + 256] = c1;
+    if (TILE_F4 > 512 && tid + 512 < TILE_F4) dst[tid + 512] = c2;
+    if (TILE_F4 > 768 && tid + 768 < TILE_F4) dst[tid + 768] = c3;
+  };
   const float* tvs = ws.tvs + (size_t)b * 3 * Vp;
   const float* vps = ws.vposed + (size_t)b * 3 * Vp;
   const float* vws = ws.vws + (size_t)b * Vp;
+  float* rv = ws.rverts + (size_t)b * 3 * Vp;
+  float nx[7];
+  int n_start = 0, n_count = 0, n_part = 0;
+  auto sload = [&](int step) {
+    if (MODE == 2) {
+      n_start = step * 64;
+      n_count = 64;
+      n_part = 0;
+    } else {
+      n_start = m.segments[step * 3];
+      n_count = m.segments[step * 3 + 1];
+      n_part = m.segments[step * 3 + 2];
+    }
+    const int i = n_start + (lane < n_count ? lane : 0);
+    nx[0] = vps[i]; nx[1] = vps[Vp + i]; nx[2] = vps[2 * Vp + i];
+    if (MODE != 2) {
+      nx[3] = tvs[i]; nx[4] = tvs[Vp + i]; nx[5] = tvs[2 * Vp + i];
+      nx[6] = WEIGHTED ? vws[i] : 1.f;
+    }
+  };
+  cload(0);
+  sload(0);
+  cstore(0);
+  __syncthreads();
   float beta[S];
 #pragma unroll
   for (int s = 0; s < S; ++s) beta[s] = sbeta[s];
   const float trans[3] = {strans[0], strans[1], strans[2]};
-
-  auto vertex = [&](int i, float* v) {
-    const sf::Skin<KW> sk = sf::load_skin<KW>(m.widx, m.wval, Vp, i);
-    const float vp[3] = {vps[i], vps[Vp + i], vps[2 * Vp + i]};
-    float sdv[3 * S];
-#pragma unroll
-    for (int k = 0; k < 3 * S; ++k) sdv[k] = m.sd[(size_t)k * Vp + i];
-    sf::lbs_vertex<S, KW>(jd, jb, sk, vp, sdv, beta, S, trans, v);
-  };
-
-  if (MODE == 2) {
-    for (int i = tid; i < Vp; i += 256) {
-      const int o = m.perm[i];
-      if (o >= 0) {
-        float v[3];
-        vertex(i, v);
-        out[((size_t)b * V + o) * 3] = v[0];
-        out[((size_t)b * V + o) * 3 + 1] = v[1];
-        out[((size_t)b * V + o) * 3 + 2] = v[2];
-      }
-    }
-    return;
-  }
-  float* rv = ws.rverts + (size_t)b * 3 * Vp;
-  const int s_begin = (int)((long)m.nseg * wave / 4), s_end = (int)((long)m.nseg * (wave + 1) / 4);
   float acc[sf::kPsum];
 #pragma unroll
   for (int k = 0; k < sf::kPsum; ++k) acc[k] = 0.f;
-  for (int s = s_begin; s < s_end; ++s) {
-    const int start = m.segments[s * 3], count = m.segments[s * 3 + 1], part = m.segments[s * 3 + 2];
-    if (lane < count) {
-      const int i = start + lane;
-      float v[3];
-      vertex(i, v);
-      if (MODE == 1) {
-        rv[i] = v[0];
-        rv[Vp + i] = v[1];
-        rv[2 * Vp + i] = v[2];
-      }
-      const float t[3] = {tvs[i], tvs[Vp + i], tvs[2 * Vp + i]};
-      sf::partsum_vertex(t, v, WEIGHTED ? vws[i] : 1.f, WEIGHTED, acc);
+  for (int step = 0; step < nsteps; ++step) {
+    const float vp[3] = {nx[0], nx[1], nx[2]};
+    const float tv[3] = {nx[3], nx[4], nx[5]};
+    const float wv = nx[6];
+    const int start = n_start, count = n_count, part = n_part;
+    if (step + 1 < nsteps) {
+      cload(step + 1);
+      sload(step + 1);
     }
-    const bool flush = (s + 1 == s_end) || (m.segments[(s + 1) * 3 + 2] != part);
+    const bool flush = MODE != 2 && ((step + 1 == nsteps) || (n_part != part));
+    if (lane < count) {
+      float v[3];
+      sf::lbs_vertex<S, KW>(jd, jb, cst + (step & 1) * 64 * CS + lane * CS, vp, beta, trans, v);
+      const int i = start + lane;
+      if (MODE == 2) {
+        const int o = m.perm[i];
+        if (o >= 0 && live) {
+          out[((size_t)b * V + o) * 3] = v[0];
+          out[((size_t)b * V + o) * 3 + 1] = v[1];
+          out[((size_t)b * V + o) * 3 + 2] = v[2];
+        }
+      } else {
+        if (MODE == 1 && live) {
+          rv[i] = v[0];
+          rv[Vp + i] = v[1];
+          rv[2 * Vp + i] = v[2];
+        }
+        sf::partsum_vertex(tv, v, wv, WEIGHTED, acc);
+      }
+    }
     if (flush) {
+      float* ps = ws.psum + ((size_t)b * J + part) * sf::kPsum;
 #pragma unroll
       for (int k = 0; k < sf::kPsum; ++k) {
-        const float r = wave_sum(acc[k]);
-        if (lane == 0) pacc[(wave * J + part) * sf::kPsum + k] = r;
+        const float r = wave_sum_last(acc[k]);
+        if (lane == 63 && live) ps[k] = r;
         acc[k] = 0.f;
       }
     }
+    if (step + 1 < nsteps) cstore((step + 1) & 1);
+    __syncthreads();
   }
-  if (MODE == 1) {
-    for (int i = m.n_used + tid; i < Vp; i += 256) {
-      float v[3] = {0.f, 0.f, 0.f};
-      if (m.perm[i] >= 0) vertex(i, v);
-      rv[i] = v[0];
-      rv[Vp + i] = v[1];
-      rv[2 * Vp + i] = v[2];
-    }
-  }
+}
+
+// the unused-part vertices of the joints-omitted path (MODE 1 stores only the used segments)
+template <int S, int KW>
+__global__ __launch_bounds__(256) void k_lbs_rest(DevModel m, Workspace ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int STRIDE = sf::jd_stride(S);
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int J = m.J, Vp = m.Vp;
+  float* jd = smem;
+  float* jb = jd + J * STRIDE;
+  for (int k = tid; k < J * STRIDE; k += 256) jd[k] = ws.jd[(size_t)b * J * STRIDE + k];
+  for (int k = tid; k < J * 4; k += 256) jb[k] = ws.jb[(size_t)b * J * 4 + k];
   __syncthreads();
-  for (int k = tid; k < J * sf::kPsum; k += 256)
-    ws.psum[(size_t)b * J * sf::kPsum + k] =
-        (pacc[k] + pacc[J * sf::kPsum + k]) + (pacc[2 * J * sf::kPsum + k] + pacc[3 * J * sf::kPsum + k]);
+  float beta[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) beta[s] = ws.beta[(size_t)b * S + s];
+  const float trans[3] = {ws.trans[b * 3], ws.trans[b * 3 + 1], ws.trans[b * 3 + 2]};
+  const float* vps = ws.vposed + (size_t)b * 3 * Vp;
+  float* rv = ws.rverts + (size_t)b * 3 * Vp;
+  for (int i = m.n_used + tid; i < Vp; i += 256) {
+    float v[3] = {0.f, 0.f, 0.f};
+    if (m.perm[i] >= 0) {
+      const float vp[3] = {vps[i], vps[Vp + i], vps[2 * Vp + i]};
+      sf::lbs_vertex<S, KW>(jd, jb, m.cpackA + (size_t)i * sf::cpack_stride(S, KW), vp, beta, trans, v);
+    }
+    rv[i] = v[0];
+    rv[Vp + i] = v[1];
+    rv[2 * Vp + i] = v[2];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -614,24 +723,31 @@ __global__ void k_copy(const float* __restrict__ src, float* __restrict__ dst, s
 // ------------------------------------------------------------------------------------------------
 template <int S, int KW>
 int launch_shape_accum(const DevModel& d, const Workspace& ws, int B, bool weighted, hipStream_t st) {
-  const size_t lds = ((size_t)d.J * sf::jd_stride(S) + 4 * (sf::ne_size(S) + 1)) * 4;
+  const size_t lds =
+      ((size_t)kNW * d.J * sf::jd_stride(S) + 2 * 64 * sf::cpack_stride(S, KW) + 256 * 12) * 4;
+  const dim3 grid((B + kNW - 1) / kNW);
   if (weighted)
-    hipLaunchKernelGGL((k_shape_accum<S, KW, true>), dim3(B), dim3(256), lds, st, d, ws);
+    hipLaunchKernelGGL((k_shape_accum<S, KW, true>), grid, dim3(256), lds, st, d, ws, B);
   else
-    hipLaunchKernelGGL((k_shape_accum<S, KW, false>), dim3(B), dim3(256), lds, st, d, ws);
+    hipLaunchKernelGGL((k_shape_accum<S, KW, false>), grid, dim3(256), lds, st, d, ws, B);
   return 0;
 }
 
 template <int S, int KW, int MODE>
 void launch_lbs(const DevModel& d, const Workspace& ws, int B, bool weighted, int nb,
                 const float* beta, const float* trans, float* out, hipStream_t st) {
-  const size_t lds = ((size_t)d.J * sf::jd_stride(S) + d.J * 4 + 4 * d.J * sf::kPsum + 36) * 4;
+  const size_t lds =
+      ((size_t)kNW * (d.J * sf::jd_stride(S) + d.J * 4 + 36) + 2 * 64 * sf::cpack_stride(S, KW)) * 4;
+  const dim3 grid((B + kNW - 1) / kNW);
   if (weighted)
-    hipLaunchKernelGGL((k_lbs_partsum<S, KW, true, MODE>), dim3(B), dim3(256), lds, st, d, ws, nb,
+    hipLaunchKernelGGL((k_lbs_partsum<S, KW, true, MODE>), grid, dim3(256), lds, st, d, ws, B, nb,
                        beta, trans, out);
   else
-    hipLaunchKernelGGL((k_lbs_partsum<S, KW, false, MODE>), dim3(B), dim3(256), lds, st, d, ws, nb,
+    hipLaunchKernelGGL((k_lbs_partsum<S, KW, false, MODE>), grid, dim3(256), lds, st, d, ws, B, nb,
                        beta, trans, out);
+  if (MODE == 1)
+    hipLaunchKernelGGL((k_lbs_rest<S, KW>), dim3(B), dim3(256),
+                       ((size_t)d.J * sf::jd_stride(S) + d.J * 4) * 4, st, d, ws);
 }
 
 #define SF_DISPATCH_SKW(d, CALL)                                               \
@@ -706,6 +822,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   ja.jw = jw;
   ja.joint_block = joints ? 1 : 0;
   ja.joint_block_weighted = eff_j ? 1 : 0;
+  ja.vertex_sa_closed_form = eff_v ? 0 : 1;
   ja.do_prologue = o.rotations_only ? 0 : 1;
   ja.fit_rotations = 1;
   if (joints) {
@@ -826,6 +943,8 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
   up(t.widx, &d.widx);
   up(t.pdT, &d.pdT);
   up(t.vtN, &d.vtN);
+  up(t.cpackA, &d.cpackA);
+  up(t.cpackB, &d.cpackB);
   up(jtemplate, &d.j_template);
   up(t.reg_start, &d.reg_start);
   up(t.reg_slot, &d.reg_slot);
@@ -844,6 +963,8 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
   up(t.adj_parts, &jt.adj_parts);
   up(t.j_ext, &jt.j_ext);
   up(t.bone_ext, &jt.bone_ext);
+  up(t.cs_joint, &jt.cs_joint);
+  up(t.cw_joint, &jt.cw_joint);
   if (rc != 0) {
     smplfit_destroy(h);
     return rc;
@@ -1011,6 +1132,7 @@ int smplfit_shape_solve_f32(const smplfit_handle* h, const float* glob_rotmats,
   ja.do_prologue = 1;
   ja.joint_block = joints ? 1 : 0;
   ja.joint_block_weighted = eff_j ? 1 : 0;
+  ja.vertex_sa_closed_form = eff_v ? 0 : 1;
   if (!joints) hipMemsetAsync(ws.tjreg, 0, (size_t)batch * d.J * 3 * 4, st);
   hipLaunchKernelGGL(k_joint_stage, dim3(batch), dim3(64), joint_lds(d), st, d, ja, ws);
   launch_gemm(d, ws, batch, st);

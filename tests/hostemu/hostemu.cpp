@@ -31,6 +31,7 @@ sf::JointTabs make_tabs(const sf::HostTables& t) {
   jt.cas_flat = t.cas_flat.data(); jt.part_type = t.part_type.data(); jt.toe_src = t.toe_src.data();
   jt.adj_level_start = t.adj_level_start.data(); jt.adj_parts = t.adj_parts.data();
   jt.j_ext = t.j_ext.data(); jt.bone_ext = t.bone_ext.data();
+  jt.cs_joint = t.cs_joint.data(); jt.cw_joint = t.cw_joint.data();
   return jt;
 }
 
@@ -60,7 +61,18 @@ struct Emu {
     float* base = scratch.data();
     while ((uintptr_t)base & 15) ++base;
     sh = sf::carve_joint_scratch(base, J, S);
+    cpack_store.assign(t.cpackA.size() + 4, 0.f);
+    float* cp = cpack_store.data();
+    while ((uintptr_t)cp & 15) ++cp;
+    std::memcpy(cp, t.cpackA.data(), t.cpackA.size() * sizeof(float));
+    cpack_aligned = cp;
   }
+
+  const float* rec(int slot) const {  // 16-byte aligned copy of the packed constants
+    return cpack_aligned + (size_t)slot * sf::cpack_stride(S, KW);
+  }
+  std::vector<float> cpack_store;
+  const float* cpack_aligned = nullptr;
 
   float* jd_b(int b) {  // 16-byte aligned per-instance joint block (stride is a multiple of 4 floats)
     float* p = jd.data();
@@ -112,14 +124,14 @@ struct Emu {
   }
 
   void k1(const float* tj, const float* rj, bool rj_shared, const float* Gprev, const float* jw,
-          bool fit_rot, bool prologue, bool jblock, bool jblock_w) {
+          bool fit_rot, bool prologue, bool jblock, bool jblock_w, bool sa_closed) {
     const int J = t.J, NE1 = sf::ne_size(S) + 1;
     HostCtx cx;
     for (int b = 0; b < B; ++b)
       sf::joint_stage(cx, jt, sh, psum.data() + (size_t)b * J * sf::kPsum, tj + (size_t)b * J * 3,
                       rj ? (rj_shared ? rj : rj + (size_t)b * J * 3) : nullptr,
                       Gprev ? Gprev + (size_t)b * J * 9 : nullptr, jw ? jw + (size_t)b * J : nullptr,
-                      fit_rot, prologue, jblock, jblock_w, G.data() + (size_t)b * J * 9,
+                      fit_rot, prologue, jblock, jblock_w, sa_closed, G.data() + (size_t)b * J * 9,
                       rp.data() + (size_t)b * t.Kp, jd_b(b), pext.data() + (size_t)b * J * 3 * (S + 1),
                       gramj.data() + (size_t)b * NE1);
   }
@@ -138,25 +150,23 @@ struct Emu {
     const int Vp = t.Vp, NE = sf::ne_size(S);
     for (int b = 0; b < B; ++b) {
       float acc[sf::ne_size(S) + 1];
+      alignas(16) float priv[12];
       for (int k = 0; k <= NE; ++k) acc[k] = 0.f;
       std::vector<double> dacc(NE + 1, 0.0);
       // accumulate in chunks so fp32 partial sums stay short, like the per-lane partials on the GPU
       for (int i0 = 0; i0 < Vp; i0 += 32) {
         for (int k = 0; k <= NE; ++k) acc[k] = 0.f;
         for (int i = i0; i < i0 + 32 && i < Vp; ++i) {
-          const sf::Skin<KW> sk = sf::load_skin<KW>(t.widx.data(), t.wval.data(), Vp, i);
           const float vp[3] = {vposed[((size_t)b * 3) * Vp + i], vposed[((size_t)b * 3 + 1) * Vp + i],
                                vposed[((size_t)b * 3 + 2) * Vp + i]};
           const float tv[3] = {tvs[((size_t)b * 3) * Vp + i], tvs[((size_t)b * 3 + 1) * Vp + i],
                                tvs[((size_t)b * 3 + 2) * Vp + i]};
-          float sdv[3 * S];
-          for (int k = 0; k < 3 * S; ++k) sdv[k] = t.sd[(size_t)k * Vp + i];
           float wv = 1.f;
           if (weighted) { wv = vws[(size_t)b * Vp + i]; acc[NE] += wv; }
           if (weighted)
-            sf::shape_accum_vertex<S, KW, true>(jd_b(b), sk, vp, tv, sdv, wv, acc);
+            sf::shape_accum_vertex<S, KW, true>(jd_b(b), rec(i), vp, tv, wv, priv, acc);
           else
-            sf::shape_accum_vertex<S, KW, false>(jd_b(b), sk, vp, tv, sdv, wv, acc);
+            sf::shape_accum_vertex<S, KW, false>(jd_b(b), rec(i), vp, tv, wv, priv, acc);
         }
         for (int k = 0; k <= NE; ++k) dacc[k] += (double)acc[k];
       }
@@ -177,16 +187,13 @@ struct Emu {
 
   void vertex(int b, int i, const float* be, int nb, const float* tr, float* v) {
     const int Vp = t.Vp;
-    const sf::Skin<KW> sk = sf::load_skin<KW>(t.widx.data(), t.wval.data(), Vp, i);
     const float vp[3] = {vposed[((size_t)b * 3) * Vp + i], vposed[((size_t)b * 3 + 1) * Vp + i],
                          vposed[((size_t)b * 3 + 2) * Vp + i]};
-    float sdv[3 * S];
-    for (int k = 0; k < 3 * S; ++k) sdv[k] = t.sd[(size_t)k * Vp + i];
     float bb[S];
     for (int s = 0; s < S; ++s) bb[s] = (be && s < nb) ? be[s] : 0.f;
     alignas(16) float jbl[sf::kMaxJoints * 4];
     std::memcpy(jbl, jb.data() + (size_t)b * t.J * 4, sizeof(float) * t.J * 4);
-    sf::lbs_vertex<S, KW>(jd_b(b), jbl, sk, vp, sdv, bb, S, tr, v);
+    sf::lbs_vertex<S, KW>(jd_b(b), jbl, rec(i), vp, bb, tr, v);
   }
 
   void k5(bool weighted, bool store) {
@@ -231,7 +238,7 @@ int fit_impl(const sf::HostTables& t, const float* tv, const float* tj, const fl
   } else {
     rj0 = jtemplate;
   }
-  e.k1(tj_rot, rj0.data(), true, nullptr, jw, true, true, joints, eff_j);
+  e.k1(tj_rot, rj0.data(), true, nullptr, jw, true, true, joints, eff_j, !eff_v);
   if (G0_out) std::memcpy(G0_out, e.G.data(), sizeof(float) * (size_t)B * t.J * 9);
   for (int it = 0; it < num_iter; ++it) {
     e.gemm();
@@ -244,7 +251,7 @@ int fit_impl(const sf::HostTables& t, const float* tv, const float* tj, const fl
     if (last) break;
     std::vector<float> Gprev = e.G;
     e.k1(tj_rot, joints ? e.rjoints.data() : e.rjreg.data(), false, Gprev.data(), jw, true, true,
-         joints, eff_j);
+         joints, eff_j, !eff_v);
   }
   HostCtx cx;
   for (int b = 0; b < B; ++b)
