@@ -57,6 +57,28 @@ SF_HD void centered_cov(const float* raw, const float* st, const float* sa, floa
       A[r * 3 + c] = raw[r * 3 + c] - st[r] * ca[c] - ct[r] * sa[c] + sw * (ct[r] * ca[c]);
 }
 
+// 1/sqrt(x) and 1/x in fp64 from the hardware seed + one Newton step on the device (the IEEE
+// sqrt / divide sequences cost ~20 dependent fp64 instructions each and dominate the latency of the
+// joint-level kernels); plain libm on the host.  Accurate to ~1e-14, far below the fp32 output.
+SF_HD double fast_rsqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y * (1.5 - 0.5 * x * y * y);
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
+SF_HD double fast_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(x);
+  r = r * (2.0 - x * r);
+  return r * (2.0 - x * r);
+#else
+  return 1.0 / x;
+#endif
+}
+
 // Nearest rotation in Frobenius norm: R = U diag(1,1,det(UV^T)) V^T of the SVD A = U S V^T
 // (rotation.py:100-110 computes it with a library SVD + reflection fix).  Closed form here, in
 // fp64: cyclic Jacobi on the symmetric M = A^T A gives V and the singular-value order; U's first two
@@ -78,7 +100,7 @@ SF_HD void proj_so3(const float* Af, float* R) {
     }
     return;
   }
-  const double inv = 1.0 / sqrt(fro2);
+  const double inv = fast_rsqrt(fro2);
   for (int k = 0; k < 9; ++k) a[k] *= inv;
   // M = A^T A (symmetric): m00 m01 m02 m11 m12 m22
   double m00 = a[0] * a[0] + a[3] * a[3] + a[6] * a[6];
@@ -90,10 +112,13 @@ SF_HD void proj_so3(const float* Af, float* R) {
   // eigenvectors as columns of V (v[r][c])
   double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
 #define SF_JACOBI(app, aqq, apq, arp, arq, vp0, vq0, vp1, vq1, vp2, vq2)                   \
-  if (fabs(apq) > 1e-300) {                                                                \
-    const double theta = (aqq - app) / (2.0 * apq);                                        \
-    const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0)); \
-    const double cc = 1.0 / sqrt(tt * tt + 1.0), ss = tt * cc;                             \
+  if (fabs(apq) > 1e-140) {                                                                \
+    /* tan of the Jacobi angle: t = e / (d + sgn(d) sqrt(d^2 + e^2)), d = aqq-app, e = 2 apq */ \
+    const double dd = aqq - app, ee = 2.0 * apq;                                           \
+    const double hh = dd * dd + ee * ee;                                                   \
+    const double rt = hh * fast_rsqrt(hh);                                                 \
+    const double tt = ee * fast_rcp(dd >= 0.0 ? dd + rt : dd - rt);                        \
+    const double cc = fast_rsqrt(tt * tt + 1.0), ss = tt * cc;                             \
     app -= tt * apq;                                                                       \
     aqq += tt * apq;                                                                       \
     apq = 0.0;                                                                             \
@@ -135,13 +160,14 @@ SF_HD void proj_so3(const float* Af, float* R) {
     u1[r] = a[r * 3] * v1[0] + a[r * 3 + 1] * v1[1] + a[r * 3 + 2] * v1[2];
     u2[r] = a[r * 3] * v2[0] + a[r * 3 + 1] * v2[1] + a[r * 3 + 2] * v2[2];
   }
-  double n1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);  // sigma1 >= 1/sqrt(3)
-  for (int r = 0; r < 3; ++r) u1[r] /= n1;
+  const double i1n = fast_rsqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);  // sigma1 >= 1/sqrt(3)
+  for (int r = 0; r < 3; ++r) u1[r] *= i1n;
   const double d12 = u2[0] * u1[0] + u2[1] * u1[1] + u2[2] * u1[2];
   for (int r = 0; r < 3; ++r) u2[r] -= d12 * u1[r];
-  double n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
-  if (n2 > 1e-14) {
-    for (int r = 0; r < 3; ++r) u2[r] /= n2;
+  double n2 = u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2];
+  if (n2 > 1e-28) {
+    const double i2n = fast_rsqrt(n2);
+    for (int r = 0; r < 3; ++r) u2[r] *= i2n;
   } else {  // rank 1: any unit vector orthogonal to u1
     int k = 0;
     if (fabs(u1[1]) < fabs(u1[k])) k = 1;
@@ -151,8 +177,8 @@ SF_HD void proj_so3(const float* Af, float* R) {
     u2[0] = u1[1] * ek[2] - u1[2] * ek[1];
     u2[1] = u1[2] * ek[0] - u1[0] * ek[2];
     u2[2] = u1[0] * ek[1] - u1[1] * ek[0];
-    n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
-    for (int r = 0; r < 3; ++r) u2[r] /= n2;
+    n2 = fast_rsqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+    for (int r = 0; r < 3; ++r) u2[r] *= n2;
   }
   u3[0] = u1[1] * u2[2] - u1[2] * u2[1];
   u3[1] = u1[2] * u2[0] - u1[0] * u2[2];

@@ -56,34 +56,38 @@ struct JointScratch {
   float *tj, *rj;  // (J,3) centred target joints / reference joints
   float *R;        // (J,9) fitted part rotations, later new rotations in the refinement
   float *G;        // (J,9) global rotations
-  float *P;        // (J,3,S+1) FK positions with beta-Jacobian
-  float *T;        // (J,3,S+1)
-  float *aux;      // (J,3) joints from betas / bones
+  float *P;        // (J,3,S+1) FK positions with beta-Jacobian          (joint stage only)
+  float *T;        // (J,3,S+1) joint stage; (J,3) bones in the refinement
+  float *aux;      // (J,3) joints from betas
   float *pos;      // (J,3)
-  double* dbl;     // solve: NE+1 sums, S*S matrix, S rhs
 };
-SF_HD int joint_scratch_floats(int J, int S) {
+// kind 0: joint stage / forward stage (P, T full).  kind 1: refinement (no P, T = (J,3)).
+SF_HD int joint_scratch_floats(int J, int S, int kind) {
   const int S1 = S + 1;
-  int f = J * 3 * 2 + J * 9 * 2 + J * 3 * S1 * 2 + J * 3 * 2;
-  f = (f + 3) / 4 * 4;
-  return f + 2 * (ne_size(S) + 1 + S * S + S + 4);
+  const int f = J * 3 * 2 + J * 9 * 2 + (kind == 0 ? J * 3 * S1 * 2 : J * 3) + J * 3 * 2;
+  return (f + 3) / 4 * 4;
 }
-SF_HD JointScratch carve_joint_scratch(float* base, int J, int S) {
+SF_HD JointScratch carve_joint_scratch(float* base, int J, int S, int kind) {
   const int S1 = S + 1;
   JointScratch s;
   s.tj = base;
   s.rj = s.tj + J * 3;
   s.R = s.rj + J * 3;
   s.G = s.R + J * 9;
-  s.P = s.G + J * 9;
-  s.T = s.P + J * 3 * S1;
-  s.aux = s.T + J * 3 * S1;
+  if (kind == 0) {
+    s.P = s.G + J * 9;
+    s.T = s.P + J * 3 * S1;
+    s.aux = s.T + J * 3 * S1;
+  } else {
+    s.P = nullptr;
+    s.T = s.G + J * 9;
+    s.aux = s.T + J * 3;
+  }
   s.pos = s.aux + J * 3;
-  int f = J * 3 * 2 + J * 9 * 2 + J * 3 * S1 * 2 + J * 3 * 2;
-  f = (f + 3) / 4 * 4;
-  s.dbl = reinterpret_cast<double*>(base + f);
   return s;
 }
+// solve stage scratch: (NE+1) + S*S + S doubles, then S+3 floats
+SF_HD int solve_scratch_floats(int S) { return 2 * (ne_size(S) + 1 + S * S + S) + ((S + 3 + 3) / 4 * 4); }
 
 #define SF_FOR(i, count) for (int i = cx.lane; i < (count); i += cx.n)
 
@@ -146,21 +150,20 @@ SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
           sw += w;
         }
         centered_cov(raw, st, sa, sw, ct, ca, A);
-        proj_so3(A, R);
       } else {
         const float* ps = psum + j * kPsum;
         centered_cov(ps, ps + 9, ps + 12, ps[15], ct, ca, A);
-        if (type == 3) {  // leaf part: Kabsch on its vertices (:1386-1387)
-          proj_so3(A, R);
-        } else {  // bone part: swing + twist (:1389-1412)
-          const int k0 = tb.cas_flat[c0], k1 = tb.cas_flat[c0 + 1];
-          float br[3], bt[3];
-          for (int c = 0; c < 3; ++c) {
-            br[c] = sh.rj[k1 * 3 + c] - sh.rj[k0 * 3 + c];
-            bt[c] = sh.tj[k1 * 3 + c] - sh.tj[k0 * 3 + c];
-          }
-          swing_twist(br, bt, A, R);
+      }
+      if (type == 2) {  // bone part: swing + twist (:1389-1412)
+        const int k0 = tb.cas_flat[c0], k1 = tb.cas_flat[c0 + 1];
+        float br[3], bt[3];
+        for (int c = 0; c < 3; ++c) {
+          br[c] = sh.rj[k1 * 3 + c] - sh.rj[k0 * 3 + c];
+          bt[c] = sh.tj[k1 * 3 + c] - sh.tj[k0 * 3 + c];
         }
+        swing_twist(br, bt, A, R);
+      } else {  // multi-joint and leaf parts: one Kabsch projection (:1386-1387), single call site
+        proj_so3(A, R);
       }
     }
     for (int k = 0; k < 9; ++k) sh.R[j * 9 + k] = R[k];
@@ -295,15 +298,16 @@ SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
 // Outputs: beta (S), trans (3), rjoints (J,3), jb (J,4) = T0 + T' beta (skinning translation).
 // ---------------------------------------------------------------------------------------------
 template <class Ctx>
-SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, const double* gramv,
+SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const double* gramv,
                        const float* gramj, const float* pext, const float* jd, float beta_reg,
                        float beta_reg2, float* beta_out, float* trans_out, float* rjoints_out,
                        float* jb_out) {
   const int J = tb.J, S = tb.S, S1 = S + 1;
   const int NG = ne_ng(S), NE = ne_size(S);
-  double* sum = sh.dbl;           // NE+1
-  double* M = sum + NE + 1;       // S*S (lower triangle used)
-  double* x = M + S * S;          // S
+  double* sum = reinterpret_cast<double*>(scratch);  // NE+1   (scratch is 8-byte aligned)
+  double* M = sum + NE + 1;                          // S*S (lower triangle used)
+  double* x = M + S * S;                             // S
+  float* aux = reinterpret_cast<float*>(x + S);      // S+3
   SF_FOR(e, NE + 1) sum[e] = gramv[e] + (double)gramj[e];
   cx.sync();
   double W = sum[NE];
@@ -348,8 +352,8 @@ SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
   }
   cx.sync();
   // translation (:1086-1088) and outputs, cast to fp32 (:1088-1089)
-  float* betaf = sh.aux;       // reuse (S <= 3J)
-  float* transf = sh.aux + S;  // 3
+  float* betaf = aux;       // S
+  float* transf = aux + S;  // 3
   SF_FOR(i, S) {
     betaf[i] = (float)x[i];
     beta_out[i] = (float)x[i];

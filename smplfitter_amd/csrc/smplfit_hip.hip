@@ -50,6 +50,7 @@ struct DevModel {
   sf::JointTabs jt;
   const int32_t* perm;      // (Vp)
   const int32_t* segments;  // (nseg,3)
+  const int32_t* part_seg_start;  // (J+1) first segment of each part (empty range: unused part)
   const float *vt, *dm, *sd, *wval, *pdT, *vtN, *j_template, *cpackA, *cpackB;
   const uint32_t* widx;
   const int32_t *reg_start, *reg_slot;
@@ -75,6 +76,22 @@ struct DevCtx {
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// DPP wave-64 sum (6 VALU ops, no LDS traffic); the total lands in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_step(float v) {
+  const int x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  return v + __builtin_bit_cast(float, x);
+}
+__device__ __forceinline__ float wave_sum_last(float v) {
+  v = dpp_step<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_step<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_step<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_step<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of each row holds the row total
+  v = dpp_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1,3
+  v = dpp_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave total
   return v;
 }
 
@@ -242,6 +259,117 @@ __global__ __launch_bounds__(256) void k_center_sort_partsum(DevModel m, const f
 }
 
 // ------------------------------------------------------------------------------------------------
+// K0 (LDS-staged form): one 1024-thread workgroup per instance.  The instance's (V,3) target row is
+// read from HBM exactly once, fully coalesced, into LDS (83 KB SMPL / 126 KB SMPL-X); the mean, the
+// gather into part-sorted SoA order and the per-part sums against the template all run out of LDS.
+// (Real SMPL vertex order is not part-sorted: gathering 12-byte vertices straight from global
+// memory pulled ~8x the row through the fabric.)   part_seg_start: (J+1) first segment of each part.
+// dynamic LDS: 3V floats + 64.
+// ------------------------------------------------------------------------------------------------
+template <bool WEIGHTED>
+__global__ __launch_bounds__(1024) void k_center_sort_partsum_lds(DevModel m, const float* __restrict__ tv,
+                                                                 const float* __restrict__ tj,
+                                                                 const float* __restrict__ vw,
+                                                                 Workspace ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int V = m.V, J = m.J, Vp = m.Vp, n3 = 3 * V;
+  float* raw = smem;                       // [3V]
+  float* red = smem + ((n3 + 3) & ~3);     // [16][3] + mu[3]
+  const float* tvb = tv + (size_t)b * n3;
+  // ---- coalesced row load (rows are 8-byte aligned: 3V*4 is a multiple of 8 when V is even)
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  if ((n3 & 1) == 0) {
+    const float2* src = reinterpret_cast<const float2*>(tvb);
+    float2* dst = reinterpret_cast<float2*>(raw);
+    for (int k = tid; k < n3 / 2; k += 1024) {
+      const float2 x = src[k];
+      dst[k] = x;
+      const int r = (2 * k) % 3;  // coordinate of x.x; x.y is (r+1)%3
+      s0 += (r == 0 ? x.x : 0.f) + (r == 2 ? x.y : 0.f);
+      s1 += (r == 1 ? x.x : 0.f) + (r == 0 ? x.y : 0.f);
+      s2 += (r == 2 ? x.x : 0.f) + (r == 1 ? x.y : 0.f);
+    }
+  } else {
+    for (int k = tid; k < n3; k += 1024) {
+      const float x = tvb[k];
+      raw[k] = x;
+      const int r = k % 3;
+      s0 += r == 0 ? x : 0.f;
+      s1 += r == 1 ? x : 0.f;
+      s2 += r == 2 ? x : 0.f;
+    }
+  }
+  if (tj) {
+    for (int j = tid; j < J; j += 1024) {
+      s0 += tj[((size_t)b * J + j) * 3];
+      s1 += tj[((size_t)b * J + j) * 3 + 1];
+      s2 += tj[((size_t)b * J + j) * 3 + 2];
+    }
+  }
+  s0 = wave_sum_last(s0);
+  s1 = wave_sum_last(s1);
+  s2 = wave_sum_last(s2);
+  if (lane == 63) {
+    red[wave * 3] = s0;
+    red[wave * 3 + 1] = s1;
+    red[wave * 3 + 2] = s2;
+  }
+  __syncthreads();
+  if (tid < 3) {
+    float s = 0.f;
+    for (int w = 0; w < 16; ++w) s += red[w * 3 + tid];
+    const float mean = s / (float)(V + (tj ? J : 0));
+    red[48 + tid] = mean;
+    ws.mean[b * 3 + tid] = mean;
+  }
+  __syncthreads();
+  const float m0 = red[48], m1 = red[49], m2 = red[50];
+  if (tj)
+    for (int k = tid; k < J * 3; k += 1024)
+      ws.tjc[(size_t)b * J * 3 + k] = tj[(size_t)b * J * 3 + k] - red[48 + k % 3];
+  // ---- gather from LDS into sorted SoA order, coalesced stores
+  float* tvs = ws.tvs + (size_t)b * 3 * Vp;
+  float* vws = ws.vws + (size_t)b * Vp;
+  for (int i = tid; i < Vp; i += 1024) {
+    const int o = m.perm[i];
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, w = 0.f;
+    if (o >= 0) {
+      t0 = raw[o * 3] - m0;
+      t1 = raw[o * 3 + 1] - m1;
+      t2 = raw[o * 3 + 2] - m2;
+      if (WEIGHTED) w = vw[(size_t)b * V + o];
+    }
+    tvs[i] = t0;
+    tvs[Vp + i] = t1;
+    tvs[2 * Vp + i] = t2;
+    if (WEIGHTED) vws[i] = w;
+  }
+  // ---- per-part sums against the template: one wave per part
+  for (int p = wave; p < J; p += 16) {
+    const int s_begin = m.part_seg_start[p], s_end = m.part_seg_start[p + 1];
+    float* ps = ws.psum + ((size_t)b * J + p) * sf::kPsum;
+    float acc[sf::kPsum];
+#pragma unroll
+    for (int k = 0; k < sf::kPsum; ++k) acc[k] = 0.f;
+    for (int s = s_begin; s < s_end; ++s) {
+      const int start = m.segments[s * 3], count = m.segments[s * 3 + 1];
+      if (lane < count) {
+        const int i = start + lane, o = m.perm[i];
+        const float t[3] = {raw[o * 3] - m0, raw[o * 3 + 1] - m1, raw[o * 3 + 2] - m2};
+        const float a[3] = {m.dm[i], m.dm[Vp + i], m.dm[2 * Vp + i]};
+        sf::partsum_vertex(t, a, WEIGHTED ? vw[(size_t)b * V + o] : 1.f, WEIGHTED, acc);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < sf::kPsum; ++k) {
+      const float r = wave_sum_last(acc[k]);
+      if (lane == 63) ps[k] = r;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // sparse post-LBS joint regression (joints-omitted path): out[b][j] = sum_k reg_val * src[b][:, slot]
 // reference: bodyfitter.py:1342-1344.  grid B, block 64.
 // ------------------------------------------------------------------------------------------------
@@ -280,7 +408,7 @@ __global__ __launch_bounds__(64) void k_joint_stage(DevModel m, JointStageArgs a
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, J = m.J, S = m.S;
   DevCtx cx{(int)threadIdx.x, 64};
-  sf::JointScratch sh = sf::carve_joint_scratch(smem, J, S);
+  sf::JointScratch sh = sf::carve_joint_scratch(smem, J, S, 0);
   const int NE1 = sf::ne_size(S) + 1;
   sf::joint_stage(cx, m.jt, sh, ws.psum + (size_t)b * J * sf::kPsum, a.tj + (size_t)b * J * 3,
                   a.rj_shared ? a.rj : a.rj + (size_t)b * J * 3,
@@ -373,22 +501,6 @@ __global__ __launch_bounds__(256) void k_posedirs_gemm(const float* __restrict__
         const int col = n0 + wn + ni * 32 + l31;
         C[(size_t)row * N + col] = acc[mi][ni][r];
       }
-}
-
-// DPP wave-64 sum (6 VALU ops, no LDS traffic); the total lands in lane 63.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_step(float v) {
-  const int x = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
-  return v + __builtin_bit_cast(float, x);
-}
-__device__ __forceinline__ float wave_sum_last(float v) {
-  v = dpp_step<0x111, 0xf>(v);  // row_shr:1
-  v = dpp_step<0x112, 0xf>(v);  // row_shr:2
-  v = dpp_step<0x114, 0xf>(v);  // row_shr:4
-  v = dpp_step<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of each row holds the row total
-  v = dpp_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1,3
-  v = dpp_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave total
-  return v;
 }
 
 constexpr int kNW = 4;  // instances (= waves) per workgroup in the vertex kernels
@@ -488,9 +600,8 @@ __global__ __launch_bounds__(64) void k_shape_solve(DevModel m, Workspace ws, fl
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, J = m.J, S = m.S;
   DevCtx cx{(int)threadIdx.x, 64};
-  sf::JointScratch sh = sf::carve_joint_scratch(smem, J, S);
   const int NE1 = sf::ne_size(S) + 1;
-  sf::solve_stage(cx, m.jt, sh, ws.gramv + (size_t)b * NE1, ws.gramj + (size_t)b * NE1,
+  sf::solve_stage(cx, m.jt, smem, ws.gramv + (size_t)b * NE1, ws.gramj + (size_t)b * NE1,
                   ws.pext + (size_t)b * J * 3 * (S + 1), ws.jd + (size_t)b * J * sf::jd_stride(S),
                   beta_reg, beta_reg2, ws.beta + (size_t)b * S, ws.trans + (size_t)b * 3,
                   ws.rjoints + (size_t)b * J * 3, ws.jb + (size_t)b * J * 4);
@@ -504,11 +615,12 @@ __global__ __launch_bounds__(64) void k_shape_solve(DevModel m, Workspace ws, fl
 // (B,V,3) (shape-solve entry point / forward) over ALL slots — no part sums.
 // dynamic LDS: 4 x (joint block rows R|T0 + jb) + 2 x (64 x cstride) constants + 4 x 36.
 // ------------------------------------------------------------------------------------------------
-template <int S, int KW, bool WEIGHTED, int MODE>
+template <int S, int KW, bool WEIGHTED, int MODE, bool SOLVE>
 __global__ __launch_bounds__(256) void k_lbs_partsum(DevModel m, Workspace ws, int B, int nb,
                                                      const float* __restrict__ beta_in,
                                                      const float* __restrict__ trans_in,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ out, float beta_reg,
+                                                     float beta_reg2) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int STRIDE = sf::jd_stride(S);
   constexpr int CS = sf::cpack_stride(S, KW), TILE_F4 = 64 * CS / 4;
@@ -517,15 +629,32 @@ __global__ __launch_bounds__(256) void k_lbs_partsum(DevModel m, Workspace ws, i
   const int b_raw = blockIdx.x * kNW + wave;
   const int b = b_raw < B ? b_raw : B - 1;
   const bool live = b_raw < B;
-  float* jd = smem + wave * (J * STRIDE + J * 4 + 36);
+  const int per_wave =
+      (J * STRIDE + J * 4 + 36 + (SOLVE ? sf::solve_scratch_floats(S) : 0) + 3) / 4 * 4;  // 16-B multiple
+  float* jd = smem + wave * per_wave;
   float* jb = jd + J * STRIDE;
   float* sbeta = jb + J * 4;   // [32]
   float* strans = sbeta + 32;  // [4]
-  float* cst = smem + kNW * (J * STRIDE + J * 4 + 36);
+  float* cst = smem + kNW * per_wave;
   {
     const float4* src = reinterpret_cast<const float4*>(ws.jd + (size_t)b * J * STRIDE);
     float4* dst = reinterpret_cast<float4*>(jd);
     for (int k = lane; k < J * STRIDE / 4; k += 64) dst[k] = src[k];
+  }
+  if (SOLVE) {
+    // K4 fused: this wave solves its instance's normal equations (fp64 centring + Cholesky) and
+    // leaves beta / trans / per-joint skinning translations in LDS for the vertex loop below.
+    // All four waves run the stage in lockstep (uniform barriers).
+    DevCtx cx{lane, 64};
+    const int NE1 = sf::ne_size(S) + 1;
+    if (lane < 32) sbeta[lane] = 0.f;
+    sf::solve_stage(cx, m.jt, strans + 4, ws.gramv + (size_t)b * NE1, ws.gramj + (size_t)b * NE1,
+                    ws.pext + (size_t)b * J * 3 * (S + 1), ws.jd + (size_t)b * J * STRIDE, beta_reg,
+                    beta_reg2, sbeta, strans, ws.rjoints + (size_t)b * J * 3, jb);
+    __syncthreads();
+    if (lane < S) ws.beta[(size_t)b * S + lane] = sbeta[lane];
+    if (lane < 3) ws.trans[(size_t)b * 3 + lane] = strans[lane];
+  } else {
     for (int k = lane; k < J * 4; k += 64) jb[k] = ws.jb[(size_t)b * J * 4 + k];
     if (lane < S) sbeta[lane] = (beta_in && lane < nb) ? beta_in[(size_t)b * nb + lane] : 0.f;
     if (lane < 3) strans[lane] = trans_in ? trans_in[(size_t)b * 3 + lane] : 0.f;
@@ -674,7 +803,7 @@ __global__ __launch_bounds__(64) void k_refine_epilogue(DevModel m, RefineArgs a
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, J = m.J, S = m.S;
   DevCtx cx{(int)threadIdx.x, 64};
-  sf::JointScratch sh = sf::carve_joint_scratch(smem, J, S);
+  sf::JointScratch sh = sf::carve_joint_scratch(smem, J, S, 1);
   sf::refine_stage(cx, m.jt, sh, ws.psum + (size_t)b * J * sf::kPsum, a.tj + (size_t)b * J * 3,
                    a.rj_term + (size_t)b * J * 3, ws.rjoints + (size_t)b * J * 3,
                    a.jw ? a.jw + (size_t)b * J : nullptr, ws.G + (size_t)b * J * 9,
@@ -697,7 +826,7 @@ __global__ __launch_bounds__(64) void k_forward_joint(DevModel m, ForwardArgs a,
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, J = m.J, S = m.S;
   DevCtx cx{(int)threadIdx.x, 64};
-  sf::JointScratch sh = sf::carve_joint_scratch(smem, J, S);
+  sf::JointScratch sh = sf::carve_joint_scratch(smem, J, S, 0);
   float* jd = ws.jd + (size_t)b * J * sf::jd_stride(S);
   sf::forward_joint_stage(cx, m.jt, sh, a.pose ? a.pose + (size_t)b * J * 3 : nullptr,
                           a.glob ? a.glob + (size_t)b * J * 9 : nullptr,
@@ -733,21 +862,49 @@ int launch_shape_accum(const DevModel& d, const Workspace& ws, int B, bool weigh
   return 0;
 }
 
-template <int S, int KW, int MODE>
+template <int S, int KW, int MODE, bool SOLVE>
 void launch_lbs(const DevModel& d, const Workspace& ws, int B, bool weighted, int nb,
-                const float* beta, const float* trans, float* out, hipStream_t st) {
-  const size_t lds =
-      ((size_t)kNW * (d.J * sf::jd_stride(S) + d.J * 4 + 36) + 2 * 64 * sf::cpack_stride(S, KW)) * 4;
+                const float* beta, const float* trans, float* out, float beta_reg, float beta_reg2,
+                hipStream_t st) {
+  const size_t per_wave =
+      ((size_t)d.J * sf::jd_stride(S) + d.J * 4 + 36 + (SOLVE ? sf::solve_scratch_floats(S) : 0) + 3) / 4 * 4;
+  const size_t lds = (kNW * per_wave + 2 * 64 * sf::cpack_stride(S, KW)) * 4;
   const dim3 grid((B + kNW - 1) / kNW);
   if (weighted)
-    hipLaunchKernelGGL((k_lbs_partsum<S, KW, true, MODE>), grid, dim3(256), lds, st, d, ws, B, nb,
-                       beta, trans, out);
+    hipLaunchKernelGGL((k_lbs_partsum<S, KW, true, MODE, SOLVE>), grid, dim3(256), lds, st, d, ws, B,
+                       nb, beta, trans, out, beta_reg, beta_reg2);
   else
-    hipLaunchKernelGGL((k_lbs_partsum<S, KW, false, MODE>), grid, dim3(256), lds, st, d, ws, B, nb,
-                       beta, trans, out);
+    hipLaunchKernelGGL((k_lbs_partsum<S, KW, false, MODE, SOLVE>), grid, dim3(256), lds, st, d, ws, B,
+                       nb, beta, trans, out, beta_reg, beta_reg2);
   if (MODE == 1)
     hipLaunchKernelGGL((k_lbs_rest<S, KW>), dim3(B), dim3(256),
                        ((size_t)d.J * sf::jd_stride(S) + d.J * 4) * 4, st, d, ws);
+}
+
+// K0 dispatch: LDS-staged form when the (V,3) row fits in LDS, gather form otherwise.
+void launch_center_sort(const DevModel& d, const float* tv, const float* tj, const float* vw,
+                        const Workspace& ws, int B, hipStream_t st) {
+  const size_t lds_row = ((size_t)((3 * d.V + 3) & ~3) + 64) * 4;
+  if (lds_row <= 160 * 1024) {
+    static bool attr_set = false;  // dynamic LDS above 64 KB has to be opted into once per kernel
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_center_sort_partsum_lds<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_center_sort_partsum_lds<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    if (vw)
+      hipLaunchKernelGGL((k_center_sort_partsum_lds<true>), dim3(B), dim3(1024), lds_row, st, d, tv, tj, vw, ws);
+    else
+      hipLaunchKernelGGL((k_center_sort_partsum_lds<false>), dim3(B), dim3(1024), lds_row, st, d, tv, tj, vw, ws);
+    return;
+  }
+  const size_t lds0 = ((size_t)4 * d.J * sf::kPsum + 20) * 4;
+  if (vw)
+    hipLaunchKernelGGL((k_center_sort_partsum<true>), dim3(B), dim3(256), lds0, st, d, tv, tj, vw, ws);
+  else
+    hipLaunchKernelGGL((k_center_sort_partsum<false>), dim3(B), dim3(256), lds0, st, d, tv, tj, vw, ws);
 }
 
 #define SF_DISPATCH_SKW(d, CALL)                                               \
@@ -778,7 +935,10 @@ int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st) {
   return 0;
 }
 
-size_t joint_lds(const DevModel& d) { return (size_t)sf::joint_scratch_floats(d.J, d.S) * 4; }
+size_t joint_lds(const DevModel& d, int kind = 0) {
+  return (size_t)sf::joint_scratch_floats(d.J, d.S, kind) * 4;
+}
+size_t solve_lds(const DevModel& d) { return (size_t)sf::solve_scratch_floats(d.S) * 4; }
 
 int post_launch_check() {
   hipError_t e = hipGetLastError();
@@ -807,11 +967,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   // joints (bodyfitter.py:1018-1028)
   const bool eff_v = joints ? (vw && jw) : (vw != nullptr);
   const bool eff_j = joints && vw && jw;
-  const size_t lds0 = ((size_t)4 * d.J * sf::kPsum + 20) * 4;
-  if (vweighted)
-    hipLaunchKernelGGL((k_center_sort_partsum<true>), dim3(B), dim3(256), lds0, st, d, tv, tj, vw, ws);
-  else
-    hipLaunchKernelGGL((k_center_sort_partsum<false>), dim3(B), dim3(256), lds0, st, d, tv, tj, vw, ws);
+  launch_center_sort(d, tv, tj, vw, ws, B, st);
   const float* tj_rot = ws.tjc;
   if (!joints) {  // regressed target joints from the centred vertices (bodyfitter.py:1342-1344)
     hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(64), 0, st, d, ws.tvs, ws.tjreg);
@@ -844,16 +1000,20 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
 #define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, B, eff_v, st)
     SF_DISPATCH_SKW(d, SF_CALL_ACCUM);
 #undef SF_CALL_ACCUM
-    hipLaunchKernelGGL(k_shape_solve, dim3(B), dim3(64), joint_lds(d), st, d, ws, o.beta_reg,
+    // K4 stays its own launch: fused into the prologue of the LBS kernel (template flag SOLVE) its
+    // ~40 serial barriers stall all four waves of the workgroup and the kernel ran 230 us longer
+    hipLaunchKernelGGL(k_shape_solve, dim3(B), dim3(64), solve_lds(d), st, d, ws, o.beta_reg,
                        o.beta_reg2);
     const bool last = it + 1 == o.num_iter;
-    if (last && !o.final_adjust) break;
+    if (last && !o.final_adjust) break;  // nothing consumes the re-evaluated mesh
     if (joints) {
-#define SF_CALL_LBS(S_, KW_) launch_lbs<S_, KW_, 0>(d, ws, B, vweighted, d.S, ws.beta, ws.trans, nullptr, st)
+#define SF_CALL_LBS(S_, KW_) \
+  launch_lbs<S_, KW_, 0, false>(d, ws, B, vweighted, d.S, ws.beta, ws.trans, nullptr, 0.f, 0.f, st)
       SF_DISPATCH_SKW(d, SF_CALL_LBS);
 #undef SF_CALL_LBS
     } else {
-#define SF_CALL_LBS(S_, KW_) launch_lbs<S_, KW_, 1>(d, ws, B, vweighted, d.S, ws.beta, ws.trans, nullptr, st)
+#define SF_CALL_LBS(S_, KW_) \
+  launch_lbs<S_, KW_, 1, false>(d, ws, B, vweighted, d.S, ws.beta, ws.trans, nullptr, 0.f, 0.f, st)
       SF_DISPATCH_SKW(d, SF_CALL_LBS);
 #undef SF_CALL_LBS
       hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(64), 0, st, d, ws.rverts, ws.rjreg);
@@ -874,7 +1034,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   ra.trans = trans;
   ra.orient = orient;
   ra.rel = rel;
-  hipLaunchKernelGGL(k_refine_epilogue, dim3(B), dim3(64), joint_lds(d), st, d, ra, ws);
+  hipLaunchKernelGGL(k_refine_epilogue, dim3(B), dim3(64), joint_lds(d, 1), st, d, ra, ws);
   return post_launch_check();
 }
 
@@ -936,6 +1096,18 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
   };
   up(t.perm, &d.perm);
   up(seg, &d.segments);
+  std::vector<int32_t> pss(t.J + 1, 0);
+  {
+    size_t k = 0;
+    for (int p = 0; p < t.J; ++p) {
+      // segments are ordered by part id over the used parts
+      while (k < t.segments.size() && t.segments[k].part < p) ++k;
+      pss[p] = (int32_t)k;
+      while (k < t.segments.size() && t.segments[k].part == p) ++k;
+      pss[p + 1] = (int32_t)k;
+    }
+  }
+  up(pss, &d.part_seg_start);
   up(t.vt, &d.vt);
   up(t.dm, &d.dm);
   up(t.sd, &d.sd);
@@ -1091,7 +1263,8 @@ int smplfit_forward_f32(const smplfit_handle* h, const float* pose_rotvecs,
   hipLaunchKernelGGL(k_forward_joint, dim3(batch), dim3(64), joint_lds(d), st, d, fa, ws);
   if (vertices) {
     launch_gemm(d, ws, batch, st);
-#define SF_CALL_LBS(S_, KW_) launch_lbs<S_, KW_, 2>(d, ws, batch, false, fa.nb, shape_betas, trans, vertices, st)
+#define SF_CALL_LBS(S_, KW_) \
+  launch_lbs<S_, KW_, 2, false>(d, ws, batch, false, fa.nb, shape_betas, trans, vertices, 0.f, 0.f, st)
     SF_DISPATCH_SKW(d, SF_CALL_LBS);
 #undef SF_CALL_LBS
   }
@@ -1115,13 +1288,7 @@ int smplfit_shape_solve_f32(const smplfit_handle* h, const float* glob_rotmats,
   const bool joints = target_joints != nullptr;
   const bool eff_v = joints ? (vertex_weights && joint_weights) : (vertex_weights != nullptr);
   const bool eff_j = joints && vertex_weights && joint_weights;
-  const size_t lds0 = ((size_t)4 * d.J * sf::kPsum + 20) * 4;
-  if (vertex_weights)
-    hipLaunchKernelGGL((k_center_sort_partsum<true>), dim3(batch), dim3(256), lds0, st, d,
-                       target_vertices, target_joints, vertex_weights, ws);
-  else
-    hipLaunchKernelGGL((k_center_sort_partsum<false>), dim3(batch), dim3(256), lds0, st, d,
-                       target_vertices, target_joints, vertex_weights, ws);
+  launch_center_sort(d, target_vertices, target_joints, vertex_weights, ws, batch, st);
   JointStageArgs ja{};
   ja.tj = joints ? ws.tjc : ws.tjreg;  // unused without the joint block
   ja.rj = nullptr;
@@ -1139,7 +1306,7 @@ int smplfit_shape_solve_f32(const smplfit_handle* h, const float* glob_rotmats,
 #define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, batch, eff_v, st)
   SF_DISPATCH_SKW(d, SF_CALL_ACCUM);
 #undef SF_CALL_ACCUM
-  hipLaunchKernelGGL(k_shape_solve, dim3(batch), dim3(64), joint_lds(d), st, d, ws, beta_regularizer,
+  hipLaunchKernelGGL(k_shape_solve, dim3(batch), dim3(64), solve_lds(d), st, d, ws, beta_regularizer,
                      beta_regularizer2);
   hipLaunchKernelGGL(k_copy, dim3(64), dim3(256), 0, st, ws.beta, shape_betas, (size_t)batch * d.S);
   hipLaunchKernelGGL(k_copy, dim3(64), dim3(256), 0, st, ws.trans, trans, (size_t)batch * 3);
@@ -1147,7 +1314,8 @@ int smplfit_shape_solve_f32(const smplfit_handle* h, const float* glob_rotmats,
     hipLaunchKernelGGL(k_copy, dim3(64), dim3(256), 0, st, ws.rjoints, joints_out,
                        (size_t)batch * d.J * 3);
   if (vertices_out) {
-#define SF_CALL_LBS(S_, KW_) launch_lbs<S_, KW_, 2>(d, ws, batch, false, d.S, ws.beta, ws.trans, vertices_out, st)
+#define SF_CALL_LBS(S_, KW_) \
+  launch_lbs<S_, KW_, 2, false>(d, ws, batch, false, d.S, ws.beta, ws.trans, vertices_out, 0.f, 0.f, st)
     SF_DISPATCH_SKW(d, SF_CALL_LBS);
 #undef SF_CALL_LBS
   }
@@ -1177,10 +1345,11 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
         return 0;
       }
       case SMPLFIT_KERNEL_SHAPE_SOLVE:
-        hipLaunchKernelGGL(k_shape_solve, dim3(batch), dim3(64), joint_lds(d), st, d, ws, 1.0f, 0.0f);
+        hipLaunchKernelGGL(k_shape_solve, dim3(batch), dim3(64), solve_lds(d), st, d, ws, 1.0f, 0.0f);
         return 0;
       case SMPLFIT_KERNEL_LBS_PARTSUM: {
-#define SF_CALL_LBS(S_, KW_) launch_lbs<S_, KW_, 0>(d, ws, batch, false, d.S, ws.beta, ws.trans, nullptr, st)
+#define SF_CALL_LBS(S_, KW_) \
+  launch_lbs<S_, KW_, 0, false>(d, ws, batch, false, d.S, ws.beta, ws.trans, nullptr, 0.f, 0.f, st)
         SF_DISPATCH_SKW(d, SF_CALL_LBS);
 #undef SF_CALL_LBS
         return 0;

@@ -44,6 +44,7 @@ struct Emu {
       rjoints, rverts, tjreg, rjreg, scratch;
   std::vector<double> gramv;
   sf::JointScratch sh;
+  std::vector<float> solve_scratch;
 
   Emu(const sf::HostTables& tt, int b) : t(tt), jt(make_tabs(tt)), B(b) {
     const int J = t.J, Vp = t.Vp, NE1 = sf::ne_size(S) + 1;
@@ -56,11 +57,12 @@ struct Emu {
     beta.assign(B * S, 0.f); trans.assign(B * 3, 0.f); jb.assign((size_t)B * J * 4, 0.f);
     rjoints.assign((size_t)B * J * 3, 0.f); rverts.assign((size_t)B * 3 * Vp, 0.f);
     tjreg.assign((size_t)B * J * 3, 0.f); rjreg.assign((size_t)B * J * 3, 0.f);
-    scratch.assign(sf::joint_scratch_floats(J, S) + 8, 0.f);
+    scratch.assign(sf::joint_scratch_floats(J, S, 0) + 8, 0.f);
+    solve_scratch.assign(sf::solve_scratch_floats(S) + 8, 0.f);
     // 16-byte align the scratch base
     float* base = scratch.data();
     while ((uintptr_t)base & 15) ++base;
-    sh = sf::carve_joint_scratch(base, J, S);
+    sh = sf::carve_joint_scratch(base, J, S, 0);
     cpack_store.assign(t.cpackA.size() + 4, 0.f);
     float* cp = cpack_store.data();
     while ((uintptr_t)cp & 15) ++cp;
@@ -73,6 +75,12 @@ struct Emu {
   }
   std::vector<float> cpack_store;
   const float* cpack_aligned = nullptr;
+
+  float* solve_base() {
+    float* p = solve_scratch.data();
+    while ((uintptr_t)p & 15) ++p;
+    return p;
+  }
 
   float* jd_b(int b) {  // 16-byte aligned per-instance joint block (stride is a multiple of 4 floats)
     float* p = jd.data();
@@ -179,7 +187,7 @@ struct Emu {
     const int J = t.J, NE1 = sf::ne_size(S) + 1;
     HostCtx cx;
     for (int b = 0; b < B; ++b)
-      sf::solve_stage(cx, jt, sh, gramv.data() + (size_t)b * NE1, gramj.data() + (size_t)b * NE1,
+      sf::solve_stage(cx, jt, solve_base(), gramv.data() + (size_t)b * NE1, gramj.data() + (size_t)b * NE1,
                       pext.data() + (size_t)b * J * 3 * (S + 1), jd_b(b), reg, reg2,
                       beta.data() + (size_t)b * S, trans.data() + (size_t)b * 3,
                       rjoints.data() + (size_t)b * J * 3, jb.data() + (size_t)b * J * 4);
