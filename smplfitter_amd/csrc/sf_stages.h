@@ -32,6 +32,11 @@ SF_HD constexpr int cpack_stride(int S, int KW) {
                                                       : (3 * S + KW + KW / 4 + 3) / 4 * 4 + 4;
 }
 
+// Position of pose-feature p inside the (Kp) GEMM K axis: parity-major, so that the fp32 MFMA
+// 32x32x2 operand of lane (row, k parity) is one contiguous run (16-byte loads).  The posedirs rows
+// (HostTables::pdT) are stored in the same order.
+SF_HD constexpr int rp_pos(int p, int Kp) { return (p & 1) * (Kp / 2) + (p >> 1); }
+
 constexpr int kPsum = 16;  // part-sum record: raw 9, s_t 3, s_a 3, s_w 1
 
 struct alignas(16) F4 {
@@ -191,10 +196,10 @@ SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
     if (j > 0) {
       float rel[9];
       m3_tmul(sh.G + tb.parents[j] * 9, sh.G + j * 9, rel);
-      for (int k = 0; k < 9; ++k) rp_out[(j - 1) * 9 + k] = rel[k];
+      for (int k = 0; k < 9; ++k) rp_out[rp_pos((j - 1) * 9 + k, tb.Kp)] = rel[k];
     }
   }
-  SF_FOR(k, tb.Kp - tb.P) rp_out[tb.P + k] = 0.f;
+  SF_FOR(k, tb.Kp - tb.P) rp_out[rp_pos(tb.P + k, tb.Kp)] = 0.f;
   SF_FOR(k, 3 * S1) sh.P[k] = tb.j_ext[k];
   cx.sync();
   // level-batched FK of positions and their beta-Jacobian (:892-907)
@@ -527,10 +532,10 @@ SF_HD void forward_joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch&
       } else {
         for (int k = 0; k < 9; ++k) rel[k] = sh.R[j * 9 + k];
       }
-      for (int k = 0; k < 9; ++k) rp_out[(j - 1) * 9 + k] = rel[k];
+      for (int k = 0; k < 9; ++k) rp_out[rp_pos((j - 1) * 9 + k, tb.Kp)] = rel[k];
     }
   }
-  SF_FOR(k, tb.Kp - tb.P) rp_out[tb.P + k] = 0.f;
+  SF_FOR(k, tb.Kp - tb.P) rp_out[rp_pos(tb.P + k, tb.Kp)] = 0.f;
   cx.sync();
   SF_FOR(c, 3) sh.pos[c] = sh.aux[c];
   cx.sync();

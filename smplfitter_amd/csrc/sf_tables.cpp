@@ -164,6 +164,8 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
   t.widx.assign((size_t)(t.KW / 4) * Vp, 0u);
   t.wval.assign((size_t)t.KW * Vp, 0.f);
   t.pdT.assign((size_t)t.Kp * 3 * Vp, 0.f);
+  const int half_k = t.Kp / 2;
+  auto kpos = [&](int p) { return (p & 1) * half_k + (p >> 1); };  // == sf::rp_pos
   for (int i = 0; i < V; ++i) {
     const int v = order[i];
     const float* w = d.weights + (size_t)v * J;
@@ -188,7 +190,7 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
       // default mesh: v_posed at identity rotations (feature = vec(I) per joint), times sum(w)
       float acc = vtc;
       for (int p = 0; p < P; ++p) {
-        t.pdT[(size_t)p * 3 * Vp + (size_t)c * Vp + i] = pd[p];
+        t.pdT[(size_t)kpos(p) * 3 * Vp + (size_t)c * Vp + i] = pd[p];
         if (p % 9 == 0 || p % 9 == 4 || p % 9 == 8) acc += pd[p];
       }
       t.dm[(size_t)c * Vp + i] = wsum * acc;
@@ -197,6 +199,14 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
     }
   }
   t.vtN = t.vt;
+  {
+    const int N = 3 * Vp, Kp = t.Kp, ntile = N / 32;
+    t.pdSw.assign((size_t)ntile * 32 * Kp, 0.f);
+    for (int nt = 0; nt < ntile; ++nt)
+      for (int n = 0; n < 32; ++n)
+        for (int k = 0; k < Kp; ++k)
+          t.pdSw[((size_t)nt * 32 + n) * Kp + k] = t.pdT[(size_t)k * N + nt * 32 + n];
+  }
   {
     const int cs = t.cstride();
     auto pack = [&](float* dst, int slot) {  // one vertex record

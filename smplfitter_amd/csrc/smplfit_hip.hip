@@ -51,7 +51,7 @@ struct DevModel {
   const int32_t* perm;      // (Vp)
   const int32_t* segments;  // (nseg,3)
   const int32_t* part_seg_start;  // (J+1) first segment of each part (empty range: unused part)
-  const float *vt, *dm, *sd, *wval, *pdT, *vtN, *j_template, *cpackA, *cpackB;
+  const float *vt, *dm, *sd, *wval, *pdT, *pdSw, *vtN, *j_template, *cpackA, *cpackB;
   const uint32_t* widx;
   const int32_t *reg_start, *reg_slot;
   const float* reg_val;
@@ -506,6 +506,92 @@ __global__ __launch_bounds__(256) void k_posedirs_gemm(const float* __restrict__
 constexpr int kNW = 4;  // instances (= waves) per workgroup in the vertex kernels
 
 // ------------------------------------------------------------------------------------------------
+// K2, A-stationary form (Kp <= 256): each wave keeps its 32 instances' whole pose-feature rows in
+// NK2 = Kp/2 VGPRs (lane = (instance, k parity), the 32x32x2 A operand) and streams 32-column tiles
+// of posedirs through a double-buffered LDS tile shared by the 4 waves (128 instances) of the
+// workgroup.  Per tile a wave issues NK2 back-to-back MFMAs on one accumulator (issue interval =
+// dependent latency = 64 cycles), fed by 16-byte LDS reads: one barrier per 6656 MFMA cycles instead
+// of one per 512 in the generic tiled kernel.  Bsw: (N/32, 32, Kp) pre-transposed tiles.
+// grid = (nchunk, Mp/128); workgroup y handles instances [128y, 128y+128), chunk x a run of tiles.
+// ------------------------------------------------------------------------------------------------
+template <int NK2>
+__global__ __launch_bounds__(256, 2) void k_posedirs_gemm_as(const float* __restrict__ A,
+                                                          const float* __restrict__ Bsw,
+                                                          const float* __restrict__ bias,
+                                                          float* __restrict__ C, int N,
+                                                          int tiles_per_chunk) {
+  constexpr int KP = 2 * NK2, RS = KP + 4;  // LDS row stride: +4 floats keeps 16 lanes on 16 slots
+  constexpr int TILE_F4 = 32 * KP / 4;      // float4 per tile in global memory
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][32][RS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lk = lane >> 5;
+  const int m0 = (blockIdx.y * 4 + wave) * 32;
+  const int ntiles = N / 32;
+  const int t_begin = blockIdx.x * tiles_per_chunk;
+  const int t_end = min(t_begin + tiles_per_chunk, ntiles);
+  // A fragment: this lane's instance row, its k parity (contiguous thanks to rp_pos)
+  float a[NK2];
+  {
+    const float4* src = reinterpret_cast<const float4*>(A + (size_t)(m0 + l31) * KP + lk * NK2);
+#pragma unroll
+    for (int q = 0; q < NK2 / 4; ++q) {
+      const float4 v = src[q];
+      a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+    }
+  }
+  // global -> register -> LDS staging of the next tile, in named registers (an indexed array would
+  // live in scratch); TILE_F4 <= 7 * 256
+  static_assert(TILE_F4 <= 7 * 256, "tile too large for the staging registers");
+  float4 s0, s1, s2, s3, s4, s5, s6;
+#define SF_STAGE_ALL(OP) OP(0, s0) OP(1, s1) OP(2, s2) OP(3, s3) OP(4, s4) OP(5, s5) OP(6, s6)
+  auto gload = [&](int tile) {
+    const float4* src = reinterpret_cast<const float4*>(Bsw) + (size_t)tile * TILE_F4;
+#define SF_LD(q, r) if (tid + 256 * q < TILE_F4) r = src[tid + 256 * q];
+    SF_STAGE_ALL(SF_LD)
+#undef SF_LD
+  };
+  auto sstore = [&](int buf) {
+    float* base = smem + (size_t)buf * 32 * RS;
+#define SF_ST(q, r)                                                                        \
+  if (tid + 256 * q < TILE_F4) {                                                           \
+    const int f = tid + 256 * q;                                                           \
+    *reinterpret_cast<float4*>(base + (f / (KP / 4)) * RS + 4 * (f % (KP / 4))) = r;      \
+  }
+    SF_STAGE_ALL(SF_ST)
+#undef SF_ST
+  };
+#undef SF_STAGE_ALL
+  if (t_begin >= t_end) return;
+  gload(t_begin);
+  sstore(0);
+  __syncthreads();
+  for (int t = t_begin; t < t_end; ++t) {
+    const int buf = (t - t_begin) & 1;
+    if (t + 1 < t_end) gload(t + 1);
+    f32x16 acc;
+    const float bv = bias[t * 32 + l31];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bv;
+    const float* brow = smem + (size_t)buf * 32 * RS + l31 * RS + lk * NK2;
+#pragma unroll
+    for (int q = 0; q < NK2 / 4; ++q) {
+      const float4 bq = *reinterpret_cast<const float4*>(brow + 4 * q);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q], bq.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 1], bq.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 2], bq.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 3], bq.w, acc, 0, 0, 0);
+    }
+    // C layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    float* crow = C + (size_t)m0 * N + t * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      crow[(size_t)((r & 3) + 8 * (r >> 2) + 4 * lk) * N] = acc[r];
+    if (t + 1 < t_end) sstore(buf ^ 1);
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K3: vertex block of the normal equations.  grid ceil(B/4), block 256: wave w fits instance
 // 4*blockIdx + w; the 4 waves walk the vertex tiles in lockstep so that the per-vertex constants
 // (shapedirs, skinning pairs: 144 B/vertex) are fetched ONCE per workgroup and staged through a
@@ -930,6 +1016,19 @@ int check_common(const smplfit_handle* h, int batch, void* workspace, size_t wor
 
 int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st) {
   const int Mp = (int)align_up((size_t)B, 128), N = 3 * d.Vp;
+  if (d.Kp == 208) {  // SMPL (J = 24): A-stationary kernel, 104 A registers per lane
+    constexpr int NK2 = 104;
+    const int ntiles = N / 32;
+    // ~768 workgroups (measured faster than exactly one 512-workgroup residency wave)
+    int nchunk = std::max(1, (3 * 256 + Mp / 128 - 1) / (Mp / 128));
+    nchunk = std::min(nchunk, ntiles);
+    const int per = (ntiles + nchunk - 1) / nchunk;
+    nchunk = (ntiles + per - 1) / per;
+    const size_t lds = (size_t)2 * 32 * (2 * NK2 + 4) * 4;
+    hipLaunchKernelGGL((k_posedirs_gemm_as<NK2>), dim3(nchunk, Mp / 128), dim3(256), lds, st, ws.rp,
+                       d.pdSw, d.vtN, ws.vposed, N, per);
+    return 0;
+  }
   hipLaunchKernelGGL(k_posedirs_gemm, dim3((N / 128) * (Mp / 128)), dim3(256), 0, st, ws.rp, d.pdT,
                      d.vtN, ws.vposed, Mp, N, d.Kp);
   return 0;
@@ -1114,6 +1213,7 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
   up(t.wval, &d.wval);
   up(t.widx, &d.widx);
   up(t.pdT, &d.pdT);
+  up(t.pdSw, &d.pdSw);
   up(t.vtN, &d.vtN);
   up(t.cpackA, &d.cpackA);
   up(t.cpackB, &d.cpackB);

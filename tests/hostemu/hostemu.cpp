@@ -149,7 +149,7 @@ struct Emu {
     for (int b = 0; b < B; ++b)
       for (int n = 0; n < N; ++n) {
         float acc = t.vtN[n];
-        for (int k = 0; k < t.P; ++k) acc = fmaf(rp[(size_t)b * t.Kp + k], t.pdT[(size_t)k * N + n], acc);
+        for (int k = 0; k < t.Kp; ++k) acc = fmaf(rp[(size_t)b * t.Kp + k], t.pdT[(size_t)k * N + n], acc);
         vposed[(size_t)b * N + n] = acc;
       }
   }
