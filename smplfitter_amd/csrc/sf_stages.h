@@ -52,6 +52,10 @@ struct JointTabs {
   const float *j_ext, *bone_ext;  // (J,3,S+1)
   const float *cs_joint;  // (J,3,S) sum_v w_vj shapedirs_v   (closed-form vertex-block SA)
   const float *cw_joint;  // (J)     sum_v w_vj
+  // pair-Gram constants (HostTables::pair_*, diag_*)
+  int np;
+  const int32_t* pair_j;
+  const float *pair_c1, *pair_c2, *pair_c3, *diag_g0, *diag_c2, *diag_c3;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -304,16 +308,28 @@ SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
 // ---------------------------------------------------------------------------------------------
 template <class Ctx>
 SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const double* gramv,
-                       const float* gramj, const float* pext, const float* jd, float beta_reg,
-                       float beta_reg2, float* beta_out, float* trans_out, float* rjoints_out,
-                       float* jb_out) {
+                       const float* gramj, const float* pext, const float* jd, const float* mb,
+                       float beta_reg, float beta_reg2, float* beta_out, float* trans_out,
+                       float* rjoints_out, float* jb_out) {
   const int J = tb.J, S = tb.S, S1 = S + 1;
   const int NG = ne_ng(S), NE = ne_size(S);
   double* sum = reinterpret_cast<double*>(scratch);  // NE+1   (scratch is 8-byte aligned)
   double* M = sum + NE + 1;                          // S*S (lower triangle used)
   double* x = M + S * S;                             // S
   float* aux = reinterpret_cast<float*>(x + S);      // S+3
-  SF_FOR(e, NE + 1) sum[e] = gramv[e] + (double)gramj[e];
+  SF_FOR(e, NE + 1) {
+    double v = gramv[e] + (double)gramj[e];
+    if (mb && e >= NG && e < NG + S) {
+      // pair-Gram form: the residual kernel delivers r1 = sum_v S_v^T (Rt_v^T b_v) and the per-joint
+      // residual moments mb_j = sum_v w_vj b_v; the T' part of Jac^T b is sum_j T'_j^T mb_j
+      const int i = e - NG, stride = jd_stride(S), row = jd_row(S);
+      double r2 = 0.0;
+      for (int j = 0; j < J; ++j)
+        for (int c = 0; c < 3; ++c) r2 += (double)jd[j * stride + 12 + c * row + i] * (double)mb[j * 3 + c];
+      v += r2;
+    }
+    sum[e] = v;
+  }
   cx.sync();
   double W = sum[NE];
   if (W == 0.0) W = 1.0;  // w_sum_safe (:1060)
@@ -719,6 +735,108 @@ SF_HD void lbs_vertex(const float* jd, const float* jb, const float* rec, const 
   for (int c = 0; c < 3; ++c)
     out[c] = (Rt[c * 3] * vs[0] + Rt[c * 3 + 1] * vs[1] + Rt[c * 3 + 2] * vs[2]) + Tb[c] +
              trans[c];
+}
+
+// Residual pass of the pair-Gram form (unit weights).  With G and SA evaluated in closed form from
+// the rotations, the vertex pass only needs Jac^T b, split as
+//   r1 = sum_v S_v^T (Rt_v^T b_v)          (accumulated here, S sums per lane)
+//   r2 = sum_j T'_j^T (sum_v w_vj b_v)     (the per-joint moments are scattered by the caller)
+// acc: [r1 : S][Sb : 3]; b_out: the residual (for the scatter).
+template <int S, int KW>
+SF_HD void residual_vertex(const float* jd, const float* rec, const float* vp, const float* tv,
+                           float* acc, float* b_out) {
+  constexpr int SD = 3 * S;
+  const Skin<KW> sk = skin_from_rec<S, KW>(rec);
+  float Rt[9], T0[3];
+  blend_rt<S, KW>(jd, sk, Rt, T0);
+  float b[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float pos = (Rt[c * 3] * vp[0] + Rt[c * 3 + 1] * vp[1] + Rt[c * 3 + 2] * vp[2]) + T0[c];
+    b[c] = tv[c] - pos;
+    b_out[c] = b[c];
+    acc[S + c] += b[c];
+  }
+  const float u[3] = {Rt[0] * b[0] + Rt[3] * b[1] + Rt[6] * b[2], Rt[1] * b[0] + Rt[4] * b[1] + Rt[7] * b[2],
+                      Rt[2] * b[0] + Rt[5] * b[1] + Rt[8] * b[2]};
+#pragma unroll
+  for (int q = 0; q < (SD + 3) / 4; ++q) {
+    const F4 t = ld4(rec + 4 * q);
+    const float f[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = 4 * q + e;
+      if (k < SD) acc[k / 3] += f[e] * u[k % 3];
+    }
+  }
+}
+
+// Pair-Gram stage: G = sum_v Jac_v^T Jac_v for unit weights, from the rotations alone.
+//   Jac_v = sum_j w_vj R_j (S_v + D_j),  D_j = R_j^T T'_j   =>
+//   G = G0 + sum_j [C2_jj^T D_j + D_j^T C2_jj + C3_jj D_j^T D_j] + sum_{j<j'} (f_jj' + f_jj'^T),
+//   f_jj'[i][i'] = sum_a ( sum_a' Q[a][a'] C1[a][a'][i][i'] + C2[a][i] U[a][i'] + D_j[a][i] V[a][i'] ),
+//   Q = R_j^T R_j',  U = Q D_j',  V = Q C2 + C3 U.
+// scratch: Qs (np*9) then Ds (J*3*S) floats.  Output: NG doubles (upper triangle, NE order).
+template <class Ctx>
+SF_HD void pair_gram_stage(Ctx& cx, const JointTabs& tb, float* scratch, const float* jd,
+                           double* G_out) {
+#define SF_FOR2(i, count) for (int i = cx.lane; i < (count); i += cx.n)
+  const int J = tb.J, S = tb.S, np = tb.np, stride = jd_stride(S), row = jd_row(S);
+  float* Qs = scratch;
+  float* Ds = scratch + np * 9;
+  SF_FOR2(idx, J * 3 * S) {
+    const int j = idx / (3 * S), a = (idx / S) % 3, i = idx % S;
+    const float* R = jd + j * stride;
+    const float* T = jd + j * stride + 12;
+    Ds[idx] = R[a] * T[i] + R[3 + a] * T[row + i] + R[6 + a] * T[2 * row + i];
+  }
+  SF_FOR2(idx, np * 9) {
+    const int p = idx / 9, a = (idx / 3) % 3, a2 = idx % 3;
+    const float* R1 = jd + tb.pair_j[2 * p] * stride;
+    const float* R2 = jd + tb.pair_j[2 * p + 1] * stride;
+    Qs[idx] = R1[a] * R2[a2] + R1[3 + a] * R2[3 + a2] + R1[6 + a] * R2[6 + a2];
+  }
+  cx.sync();
+  const int NG = ne_ng(S);
+  SF_FOR2(e, NG) {
+    int i = 0, r = e;
+    while (r >= S - i) {
+      r -= S - i;
+      ++i;
+    }
+    const int i2 = i + r;
+    float acc = tb.diag_g0[i * S + i2];
+    for (int j = 0; j < J; ++j) {
+      const float* D = Ds + j * 3 * S;
+      const float* c2 = tb.diag_c2 + j * 3 * S;
+      const float c3 = tb.diag_c3[j];
+      for (int a = 0; a < 3; ++a)
+        acc += c2[a * S + i] * D[a * S + i2] + D[a * S + i] * (c2[a * S + i2] + c3 * D[a * S + i2]);
+    }
+    for (int p = 0; p < np; ++p) {
+      const float* Q = Qs + p * 9;
+      const float* D1 = Ds + tb.pair_j[2 * p] * 3 * S;
+      const float* D2 = Ds + tb.pair_j[2 * p + 1] * 3 * S;
+      const float* c1 = tb.pair_c1 + (size_t)p * 9 * S * S;
+      const float* c2 = tb.pair_c2 + p * 3 * S;
+      const float c3 = tb.pair_c3[p];
+      // f[i][i2] + f[i2][i]
+      for (int pass = 0; pass < 2; ++pass) {
+        const int x = pass == 0 ? i : i2, y = pass == 0 ? i2 : i;
+        float f = 0.f;
+        for (int a = 0; a < 3; ++a) {
+          const float U = Q[a * 3] * D2[y] + Q[a * 3 + 1] * D2[S + y] + Q[a * 3 + 2] * D2[2 * S + y];
+          const float Vv = (Q[a * 3] * c2[y] + Q[a * 3 + 1] * c2[S + y] + Q[a * 3 + 2] * c2[2 * S + y]) + c3 * U;
+          f += (Q[a * 3] * c1[((a * 3) * S + x) * S + y] + Q[a * 3 + 1] * c1[((a * 3 + 1) * S + x) * S + y] +
+                Q[a * 3 + 2] * c1[((a * 3 + 2) * S + x) * S + y]) +
+               c2[a * S + x] * U + D1[a * S + x] * Vv;
+        }
+        acc += f;
+      }
+    }
+    G_out[e] = (double)acc;
+  }
+#undef SF_FOR2
 }
 
 // Part-sum accumulation of one vertex (_part_sums, bodyfitter.py:257-280): acc is a kPsum record.

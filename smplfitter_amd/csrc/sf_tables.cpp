@@ -270,6 +270,134 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
     for (int j = 0; j < J; ++j) t.cw_joint[j] = (float)cw[j];
   }
 
+  // ---- pair-Gram constants (double accumulation, stored fp32) ----
+  {
+    std::vector<int> pid((size_t)J * J, -1);
+    std::vector<std::pair<int, int>> plist;
+    for (int v = 0; v < V; ++v) {
+      const float* w = d.weights + (size_t)v * J;
+      for (int j = 0; j < J; ++j)
+        if (w[j] != 0.f)
+          for (int j2 = j + 1; j2 < J; ++j2)
+            if (w[j2] != 0.f && pid[(size_t)j * J + j2] < 0) {
+              pid[(size_t)j * J + j2] = 0;
+            }
+    }
+    for (int j = 0; j < J; ++j)
+      for (int j2 = j + 1; j2 < J; ++j2)
+        if (pid[(size_t)j * J + j2] == 0) {
+          pid[(size_t)j * J + j2] = (int)plist.size();
+          plist.push_back({j, j2});
+        }
+    const int np = (int)plist.size();
+    const int SS = S * S;
+    std::vector<double> c1((size_t)np * 9 * SS, 0.0), c2((size_t)np * 3 * S, 0.0), c3(np, 0.0);
+    std::vector<double> g0(SS, 0.0), dc2((size_t)J * 3 * S, 0.0), dc3(J, 0.0);
+    std::vector<double> outer((size_t)9 * SS);
+    for (int v = 0; v < V; ++v) {
+      const float* w = d.weights + (size_t)v * J;
+      const float* sv = d.shapedirs + (size_t)v * 3 * S;  // [a][i]
+      bool have_outer = false;
+      for (int j = 0; j < J; ++j) {
+        if (w[j] == 0.f) continue;
+        if (!have_outer) {
+          for (int a = 0; a < 3; ++a)
+            for (int a2 = 0; a2 < 3; ++a2)
+              for (int i = 0; i < S; ++i)
+                for (int i2 = 0; i2 < S; ++i2)
+                  outer[((size_t)(a * 3 + a2) * S + i) * S + i2] = (double)sv[a * S + i] * (double)sv[a2 * S + i2];
+          have_outer = true;
+        }
+        const double wjj = (double)w[j] * (double)w[j];
+        for (int a = 0; a < 3; ++a)
+          for (int k = 0; k < SS; ++k) g0[k] += wjj * outer[(size_t)(a * 3 + a) * SS + k];
+        for (int k = 0; k < 3 * S; ++k) dc2[(size_t)j * 3 * S + k] += wjj * (double)sv[k];
+        dc3[j] += wjj;
+        for (int j2 = j + 1; j2 < J; ++j2) {
+          if (w[j2] == 0.f) continue;
+          const int p = pid[(size_t)j * J + j2];
+          const double ww = (double)w[j] * (double)w[j2];
+          double* dst = c1.data() + (size_t)p * 9 * SS;
+          for (size_t k = 0; k < (size_t)9 * SS; ++k) dst[k] += ww * outer[k];
+          for (int k = 0; k < 3 * S; ++k) c2[(size_t)p * 3 * S + k] += ww * (double)sv[k];
+          c3[p] += ww;
+        }
+      }
+    }
+    auto tof = [](const std::vector<double>& a, std::vector<float>& o) {
+      o.resize(a.size());
+      for (size_t k = 0; k < a.size(); ++k) o[k] = (float)a[k];
+    };
+    t.pair_j.clear();
+    for (auto& pr : plist) {
+      t.pair_j.push_back(pr.first);
+      t.pair_j.push_back(pr.second);
+    }
+    tof(c1, t.pair_c1); tof(c2, t.pair_c2); tof(c3, t.pair_c3);
+    tof(g0, t.diag_g0); tof(dc2, t.diag_c2); tof(dc3, t.diag_c3);
+  }
+
+  // ---- tiles of the residual kernel: part-aligned over all slots, <= 16 distinct joints ----
+  {
+    t.gtiles.clear();
+    for (int i = 0; i < V;) {
+      const int p = t.slot_part[i];
+      int e = i;
+      uint64_t jset = 0;
+      int njoint = 0;
+      while (e < V && e - i < kTile && t.slot_part[e] == p) {
+        const float* w = d.weights + (size_t)t.perm[e] * J;
+        uint64_t add = 0;
+        for (int j = 0; j < J; ++j)
+          if (w[j] != 0.f && !((jset >> j) & 1)) add |= (uint64_t)1 << j;
+        const int nadd = __builtin_popcountll(add);
+        if (njoint + nadd > 16) break;
+        jset |= add;
+        njoint += nadd;
+        ++e;
+      }
+      if (e == i) return "smplfit_create: a vertex has more than 16 skinning joints";
+      t.gtiles.push_back({i, e - i, p});
+      i = e;
+    }
+    const int cs = t.cstride(), gs = t.gblob_stride();
+    t.gblob.assign(t.gtiles.size() * (size_t)gs, 0.f);
+    for (size_t g = 0; g < t.gtiles.size(); ++g) {
+      float* blob = t.gblob.data() + g * gs;
+      const Segment& sg = t.gtiles[g];
+      int slot_of_joint[kMaxJoints];
+      for (int j = 0; j < J; ++j) slot_of_joint[j] = -1;
+      int nslots = 0;
+      int32_t slots[16];
+      for (int k = 0; k < 16; ++k) slots[k] = J;  // padding -> dummy bin
+      for (int l = 0; l < sg.count; ++l) {
+        std::memcpy(blob + (size_t)l * cs, t.cpackA.data() + (size_t)(sg.start + l) * cs, sizeof(float) * cs);
+        const float* w = d.weights + (size_t)t.perm[sg.start + l] * J;
+        for (int j = 0; j < J; ++j)
+          if (w[j] != 0.f && slot_of_joint[j] < 0) {
+            slot_of_joint[j] = nslots;
+            slots[nslots++] = j;
+          }
+      }
+      // padded lanes keep zero records; give them a valid joint index word (joint of the part)
+      for (int l = sg.count; l < 64; ++l) {
+        uint32_t u = 0;
+        for (int k = 0; k < 4; ++k) u |= (uint32_t)sg.part << (8 * k);
+        for (int q = 0; q < t.KW / 4; ++q) std::memcpy(blob + (size_t)l * cs + 3 * S + t.KW + q, &u, 4);
+      }
+      float* wA = blob + 64 * cs;  // [16 steps][64 lanes]
+      for (int step = 0; step < 16; ++step)
+        for (int l = 0; l < 64; ++l) {
+          const int vtx = 4 * step + l / 16, slot = l % 16;
+          float val = 0.f;
+          if (vtx < sg.count && slots[slot] < J)
+            val = d.weights[(size_t)t.perm[sg.start + vtx] * J + slots[slot]];
+          wA[step * 64 + l] = val;
+        }
+      std::memcpy(blob + 64 * cs + 16 * 64, slots, sizeof(slots));
+    }
+  }
+
   // ---- sparse joint regressor over sorted slots ----
   t.has_regressor = false;
   t.reg_start.assign(1, 0);

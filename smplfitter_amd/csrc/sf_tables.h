@@ -75,6 +75,23 @@ struct HostTables {
   std::vector<float> cs_joint;  // (J,3,S) sum_v w_vj shapedirs_v  (closed-form SA of the vertex block)
   std::vector<float> cw_joint;  // (J)     sum_v w_vj
 
+  // ---- "pair-Gram" form of the shape solve (unit weights): the Gramian of the vertex block
+  // depends on the rotations only, G = sum over joint pairs of small contractions with these
+  // constants; off-diagonal pairs j < j' that share at least one vertex:
+  std::vector<int32_t> pair_j;   // (np, 2)
+  std::vector<float> pair_c1;    // (np, 9, S, S)  sum_v w_vj w_vj' S_v[a][i] S_v[a'][i'],  [a*3+a'][i][i']
+  std::vector<float> pair_c2;    // (np, 3, S)     sum_v w_vj w_vj' S_v[a][i]
+  std::vector<float> pair_c3;    // (np)           sum_v w_vj w_vj'
+  std::vector<float> diag_g0;    // (S, S)  sum_j sum_a C1_jj[a][a][i][i']   (R_j^T R_j = I)
+  std::vector<float> diag_c2;    // (J, 3, S)
+  std::vector<float> diag_c3;    // (J)
+  // tiles of the residual kernel: part-aligned, <= 64 vertices, <= 16 distinct joints, over ALL
+  // slots; blob per tile = [64 x cstride() vertex records | 16 x 64 MFMA A-operand weights
+  // (step t, lane l -> weight of vertex 4t + l/16 for joint slot l%16) | 16 joint ids (pad = J)]
+  std::vector<Segment> gtiles;
+  std::vector<float> gblob;      // (ngt, gblob_stride())
+  int gblob_stride() const { return 64 * cstride() + 16 * 64 + 16; }
+
   // sparse post-LBS joint regressor, CSR over sorted slots (joints-omitted path)
   std::vector<int32_t> reg_start, reg_slot;
   std::vector<float> reg_val;

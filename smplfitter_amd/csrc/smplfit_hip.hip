@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -51,7 +52,9 @@ struct DevModel {
   const int32_t* perm;      // (Vp)
   const int32_t* segments;  // (nseg,3)
   const int32_t* part_seg_start;  // (J+1) first segment of each part (empty range: unused part)
-  const float *vt, *dm, *sd, *wval, *pdT, *pdSw, *vtN, *j_template, *cpackA, *cpackB;
+  const float *vt, *dm, *sd, *wval, *pdT, *pdSw, *vtN, *j_template, *cpackA, *cpackB, *gblob;
+  const int32_t* gtiles;  // (ngt,3) start, count, part
+  int ngt;
   const uint32_t* widx;
   const int32_t *reg_start, *reg_slot;
   const float* reg_val;
@@ -116,6 +119,7 @@ struct Workspace {
   float* rverts;   // (B,3,Vp) re-evaluated vertices (joints-omitted path only)
   float* tjreg;    // (B,J,3) regressed target joints (joints-omitted path)
   float* rjreg;    // (B,J,3) regressed reference joints
+  float* mbj;      // (B,J,3) per-joint residual moments (pair-Gram form)
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -149,6 +153,7 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w) {
   ws.rverts = (float*)take((size_t)B * 3 * Vp * 4);
   ws.tjreg = (float*)take((size_t)B * J * 3 * 4);
   ws.rjreg = (float*)take((size_t)B * J * 3 * 4);
+  ws.mbj = (float*)take((size_t)B * J * 3 * 4);
   if (w) *w = ws;
   return off;
 }
@@ -679,18 +684,163 @@ __global__ __launch_bounds__(256, 2) void k_shape_accum(DevModel m, Workspace ws
 }
 
 // ------------------------------------------------------------------------------------------------
+// K3r: residual pass of the pair-Gram form (unit weights).  grid ceil(B/4), block 256, wave =
+// instance, lockstep over the residual tiles (part-aligned, <= 16 distinct joints) whose constants
+// blob [vertex records | MFMA A-operand weights | joint ids] is staged through double-buffered LDS.
+// Per vertex ~115 FMAs: blended R/T0, residual b, u = Rt^T b, r1 += S_v^T u, Sb += b.  The per-joint
+// residual moments mb_j = sum_v w_vj b_v (a scatter over the 4 skinning joints of every vertex) run on
+// the otherwise idle matrix pipe: D(16 joint slots x 16) += W(16 x 4 vertices) . b(4 x 16) with
+// v_mfma_f32_16x16x4_f32, 16 instructions per 64-vertex tile, then 3x4 lanes add D into the wave's LDS
+// bins — deterministic, no atomics.
+// dynamic LDS: 4 x [jd | bbuf 256 | bins (J+1)*4] + 2 blobs.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int S, int KW>
+__global__ __launch_bounds__(256) void k_residual(DevModel m, Workspace ws, int B) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NE = sf::ne_size(S), NG = sf::ne_ng(S), STRIDE = sf::jd_stride(S);
+  constexpr int CS = sf::cpack_stride(S, KW), BLOB = 64 * CS + 16 * 64 + 16, BLOB_F4 = BLOB / 4;
+  static_assert(BLOB % 4 == 0 && BLOB_F4 <= 1280, "blob staging");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int J = m.J, Vp = m.Vp;
+  const int b_raw = blockIdx.x * kNW + wave;
+  const int b = b_raw < B ? b_raw : B - 1;
+  const int per_wave = (J * STRIDE + 256 + (J + 1) * 4 + 3) / 4 * 4;
+  float* jd = smem + wave * per_wave;
+  float* bbuf = jd + J * STRIDE;  // [64][4]
+  float* bins = bbuf + 256;       // [(J+1)][4]
+  float* blob = smem + kNW * per_wave;  // [2][BLOB]
+  {
+    const float4* src = reinterpret_cast<const float4*>(ws.jd + (size_t)b * J * STRIDE);
+    float4* dst = reinterpret_cast<float4*>(jd);
+    for (int k = lane; k < J * STRIDE / 4; k += 64) dst[k] = src[k];
+    for (int k = lane; k < (J + 1) * 4; k += 64) bins[k] = 0.f;
+  }
+  const float4* cg = reinterpret_cast<const float4*>(m.gblob);
+  const float* tvs = ws.tvs + (size_t)b * 3 * Vp;
+  const float* vps = ws.vposed + (size_t)b * 3 * Vp;
+  // Two register stages (A, B), each holding one tile's constants-blob slice + this lane's target /
+  // v_posed values; a stage is (re)loaded TWO tiles ahead of its use so that HBM / L2 latency is
+  // covered by two tiles of work (one tile ahead left the loop latency-bound).  Named registers and
+  // macros: a struct passed to a lambda ends up in scratch memory.
+  float4 cA0, cA1, cA2, cA3, cA4, cB0, cB1, cB2, cB3, cB4;
+  float vA0, vA1, vA2, tA0, tA1, tA2, vB0, vB1, vB2, tB0, tB1, tB2;
+#define SF_ISSUE(P, tile_)                                                                     \
+  do {                                                                                         \
+    const float4* src_ = cg + (size_t)(tile_) * BLOB_F4;                                       \
+    c##P##0 = src_[tid];                                                                       \
+    if (BLOB_F4 > 256 && tid + 256 < BLOB_F4) c##P##1 = src_[tid + 256];                       \
+    if (BLOB_F4 > 512 && tid + 512 < BLOB_F4) c##P##2 = src_[tid + 512];                       \
+    if (BLOB_F4 > 768 && tid + 768 < BLOB_F4) c##P##3 = src_[tid + 768];                       \
+    if (BLOB_F4 > 1024 && tid + 1024 < BLOB_F4) c##P##4 = src_[tid + 1024];                    \
+    const int start_ = m.gtiles[(tile_) * 3], count_ = m.gtiles[(tile_) * 3 + 1];              \
+    const int i_ = start_ + (lane < count_ ? lane : 0);                                        \
+    const float keep_ = lane < count_ ? 1.f : 0.f; /* padding lanes: zero residual */          \
+    v##P##0 = vps[i_] * keep_; v##P##1 = vps[Vp + i_] * keep_; v##P##2 = vps[2 * Vp + i_] * keep_; \
+    t##P##0 = tvs[i_] * keep_; t##P##1 = tvs[Vp + i_] * keep_; t##P##2 = tvs[2 * Vp + i_] * keep_; \
+  } while (0)
+#define SF_COMMIT(P, buf_)                                                                     \
+  do {                                                                                         \
+    float4* dst_ = reinterpret_cast<float4*>(blob + (buf_) * BLOB);                            \
+    dst_[tid] = c##P##0;                                                                       \
+    if (BLOB_F4 > 256 && tid + 256 < BLOB_F4) dst_[tid + 256] = c##P##1;                       \
+    if (BLOB_F4 > 512 && tid + 512 < BLOB_F4) dst_[tid + 512] = c##P##2;                       \
+    if (BLOB_F4 > 768 && tid + 768 < BLOB_F4) dst_[tid + 768] = c##P##3;                       \
+    if (BLOB_F4 > 1024 && tid + 1024 < BLOB_F4) dst_[tid + 1024] = c##P##4;                    \
+  } while (0)
+  float acc[S + 3];
+#pragma unroll
+  for (int k = 0; k < S + 3; ++k) acc[k] = 0.f;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int bsel = l15 < 3 ? l15 : 3;  // B-operand column: coordinate, columns >= 3 read the zero pad
+  auto compute = [&](int buf, const float* vp, const float* tv) {
+    const float* cur = blob + buf * BLOB;
+    float bo[3];
+    sf::residual_vertex<S, KW>(jd, cur + lane * CS, vp, tv, acc, bo);
+    *reinterpret_cast<float4*>(bbuf + lane * 4) = make_float4(bo[0], bo[1], bo[2], 0.f);
+    // scatter on the matrix pipe: D[slot][coord] += sum_vertex W[slot][vertex] b[vertex][coord]
+    const float* wA = cur + 64 * CS;
+    f32x4 D0 = {0.f, 0.f, 0.f, 0.f}, D1 = {0.f, 0.f, 0.f, 0.f};  // two chains: 40-cycle dependent latency
+#pragma unroll
+    for (int t = 0; t < 16; t += 2) {
+      D0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[t * 64 + lane], bbuf[(4 * t + l4) * 4 + bsel], D0, 0, 0, 0);
+      D1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[(t + 1) * 64 + lane], bbuf[(4 * t + 4 + l4) * 4 + bsel], D1, 0, 0, 0);
+    }
+    if (l15 < 3) {  // C/D layout 16x16: col = lane & 15, row = (lane >> 4) * 4 + r
+      const int* slots = reinterpret_cast<const int*>(cur + 64 * CS + 16 * 64);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bins[slots[l4 * 4 + r] * 4 + l15] += D0[r] + D1[r];
+    }
+  };
+  const int ntiles = m.ngt;
+  SF_ISSUE(A, 0);
+  if (ntiles > 1) SF_ISSUE(B, 1);
+  SF_COMMIT(A, 0);
+  __syncthreads();
+  for (int tile = 0; tile < ntiles; tile += 2) {
+    {
+      const float vp[3] = {vA0, vA1, vA2}, tv[3] = {tA0, tA1, tA2};
+      if (tile + 2 < ntiles) SF_ISSUE(A, tile + 2);
+      compute(0, vp, tv);
+      if (tile + 1 < ntiles) SF_COMMIT(B, 1);
+      __syncthreads();
+    }
+    if (tile + 1 >= ntiles) break;
+    {
+      const float vp[3] = {vB0, vB1, vB2}, tv[3] = {tB0, tB1, tB2};
+      if (tile + 3 < ntiles) SF_ISSUE(B, tile + 3);
+      compute(1, vp, tv);
+      if (tile + 2 < ntiles) SF_COMMIT(A, 0);
+      __syncthreads();
+    }
+  }
+#undef SF_ISSUE
+#undef SF_COMMIT
+  double* out = ws.gramv + (size_t)b * (NE + 1);
+#pragma unroll
+  for (int k = 0; k < S + 3; ++k) {
+    const float r = wave_sum_last(acc[k]);
+    if (lane == 63 && b_raw < B) out[k < S ? NG + k : NG + 4 * S + (k - S)] = (double)r;
+  }
+  if (b_raw < B) {
+    if (lane == 63) out[NE] = (double)m.V;  // w_sum = num_vertices (bodyfitter.py:1038-1040)
+    for (int k = lane; k < 3 * S; k += 64) out[NG + S + k] = 0.0;  // SA: closed form in the joint stage
+    for (int k = lane; k < J * 3; k += 64) ws.mbj[(size_t)b * J * 3 + k] = bins[(k / 3) * 4 + k % 3];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3g: pair-Gram — the S x S Gramian of the vertex block from the rotations alone (unit weights).
+// grid B, block 64 (one wave per instance, lanes = upper-triangle entries).  Independent of the
+// targets and of the GEMM: it can run on a second stream next to K2.
+// dynamic LDS: joint block + np*9 + J*3*S floats.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_pair_gram(DevModel m, Workspace ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, J = m.J, S = m.S, stride = sf::jd_stride(S);
+  DevCtx cx{(int)threadIdx.x, 64};
+  float* jd = smem;
+  float* scratch = smem + J * stride;
+  for (int k = threadIdx.x; k < J * stride; k += 64) jd[k] = ws.jd[(size_t)b * J * stride + k];
+  __syncthreads();
+  sf::pair_gram_stage(cx, m.jt, scratch, jd, ws.gramv + (size_t)b * (sf::ne_size(S) + 1));
+}
+
+// ------------------------------------------------------------------------------------------------
 // K4: solve.  grid B, block 64.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_shape_solve(DevModel m, Workspace ws, float beta_reg,
-                                                    float beta_reg2) {
+                                                    float beta_reg2, int pair_form) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, J = m.J, S = m.S;
   DevCtx cx{(int)threadIdx.x, 64};
   const int NE1 = sf::ne_size(S) + 1;
   sf::solve_stage(cx, m.jt, smem, ws.gramv + (size_t)b * NE1, ws.gramj + (size_t)b * NE1,
                   ws.pext + (size_t)b * J * 3 * (S + 1), ws.jd + (size_t)b * J * sf::jd_stride(S),
-                  beta_reg, beta_reg2, ws.beta + (size_t)b * S, ws.trans + (size_t)b * 3,
-                  ws.rjoints + (size_t)b * J * 3, ws.jb + (size_t)b * J * 4);
+                  pair_form ? ws.mbj + (size_t)b * J * 3 : nullptr, beta_reg, beta_reg2,
+                  ws.beta + (size_t)b * S, ws.trans + (size_t)b * 3, ws.rjoints + (size_t)b * J * 3,
+                  ws.jb + (size_t)b * J * 4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -735,8 +885,8 @@ __global__ __launch_bounds__(256) void k_lbs_partsum(DevModel m, Workspace ws, i
     const int NE1 = sf::ne_size(S) + 1;
     if (lane < 32) sbeta[lane] = 0.f;
     sf::solve_stage(cx, m.jt, strans + 4, ws.gramv + (size_t)b * NE1, ws.gramj + (size_t)b * NE1,
-                    ws.pext + (size_t)b * J * 3 * (S + 1), ws.jd + (size_t)b * J * STRIDE, beta_reg,
-                    beta_reg2, sbeta, strans, ws.rjoints + (size_t)b * J * 3, jb);
+                    ws.pext + (size_t)b * J * 3 * (S + 1), ws.jd + (size_t)b * J * STRIDE, nullptr,
+                    beta_reg, beta_reg2, sbeta, strans, ws.rjoints + (size_t)b * J * 3, jb);
     __syncthreads();
     if (lane < S) ws.beta[(size_t)b * S + lane] = sbeta[lane];
     if (lane < 3) ws.trans[(size_t)b * 3 + lane] = strans[lane];
@@ -936,15 +1086,35 @@ __global__ void k_copy(const float* __restrict__ src, float* __restrict__ dst, s
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
+// The unit-weight vertex block has two implementations:
+//   direct (default): k_shape_accum accumulates G, r, Sb per vertex (VALU-bound);
+//   pair  (SMPLFIT_SHAPE_FORM=pair): k_residual + k_pair_gram — 4x fewer per-vertex FLOPs, parity-tested,
+//          but not yet faster: the residual pass is bound by the memory system.
+bool use_pair_form() {
+  static const bool pair = [] {
+    const char* e = getenv("SMPLFIT_SHAPE_FORM");
+    return e && std::string(e) == "pair";
+  }();
+  return pair;
+}
+
 template <int S, int KW>
 int launch_shape_accum(const DevModel& d, const Workspace& ws, int B, bool weighted, hipStream_t st) {
-  const size_t lds =
-      ((size_t)kNW * d.J * sf::jd_stride(S) + 2 * 64 * sf::cpack_stride(S, KW) + 256 * 12) * 4;
   const dim3 grid((B + kNW - 1) / kNW);
-  if (weighted)
-    hipLaunchKernelGGL((k_shape_accum<S, KW, true>), grid, dim3(256), lds, st, d, ws, B);
-  else
-    hipLaunchKernelGGL((k_shape_accum<S, KW, false>), grid, dim3(256), lds, st, d, ws, B);
+  if (weighted || !use_pair_form()) {
+    const size_t lds =
+        ((size_t)kNW * d.J * sf::jd_stride(S) + 2 * 64 * sf::cpack_stride(S, KW) + 256 * 12) * 4;
+    if (weighted)
+      hipLaunchKernelGGL((k_shape_accum<S, KW, true>), grid, dim3(256), lds, st, d, ws, B);
+    else
+      hipLaunchKernelGGL((k_shape_accum<S, KW, false>), grid, dim3(256), lds, st, d, ws, B);
+    return 0;
+  }
+  const size_t per_wave = ((size_t)d.J * sf::jd_stride(S) + 256 + (d.J + 1) * 4 + 3) / 4 * 4;
+  const size_t blob = 64 * sf::cpack_stride(S, KW) + 16 * 64 + 16;
+  hipLaunchKernelGGL((k_residual<S, KW>), grid, dim3(256), (kNW * per_wave + 2 * blob) * 4, st, d, ws, B);
+  const size_t lds_g = ((size_t)d.J * sf::jd_stride(S) + (size_t)d.jt.np * 9 + (size_t)d.J * 3 * S) * 4;
+  hipLaunchKernelGGL(k_pair_gram, dim3(B), dim3(64), lds_g, st, d, ws);
   return 0;
 }
 
@@ -1102,7 +1272,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     // K4 stays its own launch: fused into the prologue of the LBS kernel (template flag SOLVE) its
     // ~40 serial barriers stall all four waves of the workgroup and the kernel ran 230 us longer
     hipLaunchKernelGGL(k_shape_solve, dim3(B), dim3(64), solve_lds(d), st, d, ws, o.beta_reg,
-                       o.beta_reg2);
+                       o.beta_reg2, (!eff_v && use_pair_form()) ? 1 : 0);
     const bool last = it + 1 == o.num_iter;
     if (last && !o.final_adjust) break;  // nothing consumes the re-evaluated mesh
     if (joints) {
@@ -1217,6 +1387,15 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
   up(t.vtN, &d.vtN);
   up(t.cpackA, &d.cpackA);
   up(t.cpackB, &d.cpackB);
+  up(t.gblob, &d.gblob);
+  std::vector<int32_t> gt;
+  for (auto& g : t.gtiles) {
+    gt.push_back(g.start);
+    gt.push_back(g.count);
+    gt.push_back(g.part);
+  }
+  up(gt, &d.gtiles);
+  d.ngt = (int)t.gtiles.size();
   up(jtemplate, &d.j_template);
   up(t.reg_start, &d.reg_start);
   up(t.reg_slot, &d.reg_slot);
@@ -1237,6 +1416,14 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
   up(t.bone_ext, &jt.bone_ext);
   up(t.cs_joint, &jt.cs_joint);
   up(t.cw_joint, &jt.cw_joint);
+  jt.np = (int)t.pair_c3.size();
+  up(t.pair_j, &jt.pair_j);
+  up(t.pair_c1, &jt.pair_c1);
+  up(t.pair_c2, &jt.pair_c2);
+  up(t.pair_c3, &jt.pair_c3);
+  up(t.diag_g0, &jt.diag_g0);
+  up(t.diag_c2, &jt.diag_c2);
+  up(t.diag_c3, &jt.diag_c3);
   if (rc != 0) {
     smplfit_destroy(h);
     return rc;
@@ -1407,7 +1594,7 @@ int smplfit_shape_solve_f32(const smplfit_handle* h, const float* glob_rotmats,
   SF_DISPATCH_SKW(d, SF_CALL_ACCUM);
 #undef SF_CALL_ACCUM
   hipLaunchKernelGGL(k_shape_solve, dim3(batch), dim3(64), solve_lds(d), st, d, ws, beta_regularizer,
-                     beta_regularizer2);
+                     beta_regularizer2, (!eff_v && use_pair_form()) ? 1 : 0);
   hipLaunchKernelGGL(k_copy, dim3(64), dim3(256), 0, st, ws.beta, shape_betas, (size_t)batch * d.S);
   hipLaunchKernelGGL(k_copy, dim3(64), dim3(256), 0, st, ws.trans, trans, (size_t)batch * 3);
   if (joints_out)
@@ -1445,7 +1632,8 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
         return 0;
       }
       case SMPLFIT_KERNEL_SHAPE_SOLVE:
-        hipLaunchKernelGGL(k_shape_solve, dim3(batch), dim3(64), solve_lds(d), st, d, ws, 1.0f, 0.0f);
+        hipLaunchKernelGGL(k_shape_solve, dim3(batch), dim3(64), solve_lds(d), st, d, ws, 1.0f, 0.0f,
+                           use_pair_form() ? 1 : 0);
         return 0;
       case SMPLFIT_KERNEL_LBS_PARTSUM: {
 #define SF_CALL_LBS(S_, KW_) \

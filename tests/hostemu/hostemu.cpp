@@ -32,6 +32,9 @@ sf::JointTabs make_tabs(const sf::HostTables& t) {
   jt.adj_level_start = t.adj_level_start.data(); jt.adj_parts = t.adj_parts.data();
   jt.j_ext = t.j_ext.data(); jt.bone_ext = t.bone_ext.data();
   jt.cs_joint = t.cs_joint.data(); jt.cw_joint = t.cw_joint.data();
+  jt.np = (int)t.pair_c3.size(); jt.pair_j = t.pair_j.data(); jt.pair_c1 = t.pair_c1.data();
+  jt.pair_c2 = t.pair_c2.data(); jt.pair_c3 = t.pair_c3.data(); jt.diag_g0 = t.diag_g0.data();
+  jt.diag_c2 = t.diag_c2.data(); jt.diag_c3 = t.diag_c3.data();
   return jt;
 }
 
@@ -154,7 +157,44 @@ struct Emu {
       }
   }
 
+  std::vector<float> mbj;  // (B,J,3) per-joint residual moments of the pair-Gram form
+  bool use_pair_gram = false;
+
+  void k3_pair(void) {  // unit weights: residual pass + pair-Gram (mirrors k_residual / k_pair_gram)
+    const int Vp = t.Vp, NE = sf::ne_size(S), NG = sf::ne_ng(S), J = t.J;
+    mbj.assign((size_t)B * J * 3, 0.f);
+    std::vector<float> pscratch((size_t)jt.np * 9 + (size_t)J * 3 * S + 8);
+    HostCtx cx;
+    for (int b = 0; b < B; ++b) {
+      std::vector<double> dacc(NE + 1, 0.0);
+      for (const auto& g : t.gtiles) {  // per-tile fp32 partials, like the per-lane partials on the GPU
+        float acc[S + 3];
+        for (int k = 0; k < S + 3; ++k) acc[k] = 0.f;
+        for (int l = 0; l < g.count; ++l) {
+          const int i = g.start + l;
+          const float vp[3] = {vposed[((size_t)b * 3) * Vp + i], vposed[((size_t)b * 3 + 1) * Vp + i],
+                               vposed[((size_t)b * 3 + 2) * Vp + i]};
+          const float tv[3] = {tvs[((size_t)b * 3) * Vp + i], tvs[((size_t)b * 3 + 1) * Vp + i],
+                               tvs[((size_t)b * 3 + 2) * Vp + i]};
+          float bo[3];
+          sf::residual_vertex<S, KW>(jd_b(b), rec(i), vp, tv, acc, bo);
+          const sf::Skin<KW> sk = sf::skin_from_rec<S, KW>(rec(i));
+          for (int k = 0; k < KW; ++k)
+            for (int c = 0; c < 3; ++c) mbj[((size_t)b * J + sk.j[k]) * 3 + c] += sk.w[k] * bo[c];
+        }
+        for (int k = 0; k < S; ++k) dacc[NG + k] += (double)acc[k];
+        for (int c = 0; c < 3; ++c) dacc[NG + 4 * S + c] += (double)acc[S + c];
+      }
+      dacc[NE] = (double)t.V;
+      sf::pair_gram_stage(cx, jt, pscratch.data(), jd_b(b), dacc.data());
+      for (int k = 0; k <= NE; ++k) gramv[(size_t)b * (NE + 1) + k] = dacc[k];
+    }
+    use_pair_gram = true;
+  }
+
   void k3(bool weighted) {
+    if (!weighted) { k3_pair(); return; }
+    use_pair_gram = false;
     const int Vp = t.Vp, NE = sf::ne_size(S);
     for (int b = 0; b < B; ++b) {
       float acc[sf::ne_size(S) + 1];
@@ -188,7 +228,8 @@ struct Emu {
     HostCtx cx;
     for (int b = 0; b < B; ++b)
       sf::solve_stage(cx, jt, solve_base(), gramv.data() + (size_t)b * NE1, gramj.data() + (size_t)b * NE1,
-                      pext.data() + (size_t)b * J * 3 * (S + 1), jd_b(b), reg, reg2,
+                      pext.data() + (size_t)b * J * 3 * (S + 1), jd_b(b),
+                      use_pair_gram ? mbj.data() + (size_t)b * J * 3 : nullptr, reg, reg2,
                       beta.data() + (size_t)b * S, trans.data() + (size_t)b * 3,
                       rjoints.data() + (size_t)b * J * 3, jb.data() + (size_t)b * J * 4);
   }

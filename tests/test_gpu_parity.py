@@ -187,3 +187,45 @@ def test_full_size_properties(name, B, model_root, golden, dev):
     eye = torch.eye(3, device=dev)
     assert (R @ R.transpose(-1, -2) - eye).abs().max().item() < 1e-5
     assert (torch.linalg.det(R) - 1).abs().max().item() < 1e-5
+
+
+def test_pair_gram_form(model_root):
+    """The alternative unit-weight shape solve (k_residual + k_pair_gram, SMPLFIT_SHAPE_FORM=pair:
+    Gramian from joint-pair constants, residual moments scattered on the matrix pipe) must give the
+    same answers as the golden vectors.  The switch is read once per process -> subprocess."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "tests")
+import util
+from smplfitter_amd.pt import BodyFitter, BodyModel
+root = sys.argv[1]
+for name, kind in (("smpl", "smpl"), ("smplx", "smplx")):
+    g = dict(np.load(f"tests/golden/golden_{name}.npz"))
+    kind, md = util.load_md(root, name, g)
+    om64, _ = util.make_oracle(md, kind, np.float64)
+    m = BodyModel(kind, "neutral", model_root=f"{root}/{kind}", num_betas=10, device="cuda:0")
+    f = BodyFitter(m)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    for c in util.fit_configs(g):
+        cfg = util.cfg_from_name(c)
+        if cfg["weights"]:
+            continue
+        o = f.fit(t(g["target_vertices"]), t(g["target_joints"]) if cfg["joints"] else None,
+                  num_iter=cfg["num_iter"], beta_regularizer=cfg["beta_regularizer"],
+                  final_adjust_rots=cfg["final_adjust_rots"])
+        o = {k: v.cpu().numpy() for k, v in o.items()}
+        ref = {k: g[f"fit.{c}.{k}"] for k in ("pose_rotvecs", "shape_betas", "trans")}
+        assert util.vertex_l2(om64, o, ref) < 1e-4, (name, c)
+        assert np.abs(o["shape_betas"] - ref["shape_betas"]).max() < 3e-4, (name, c)
+        assert np.abs(o["trans"] - ref["trans"]).max() < 1e-5, (name, c)
+print("PAIR_FORM_OK")
+'''
+    env = dict(os.environ, SMPLFIT_SHAPE_FORM='pair')
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', code, model_root], cwd=root_dir, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert 'PAIR_FORM_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,5 +1,6 @@
-"""Experiment: split the batch over several HIP streams (separate workspaces) and see whether the
-MFMA-bound GEMM of one chunk overlaps the VALU-bound vertex kernels of another."""
+"""Experiment: process the batch in chunks, round-robin over several HIP streams (separate workspaces
+per stream), to see (a) MFMA/VALU overlap across streams and (b) Infinity-Cache residency of a
+chunk's streams when the chunk loop is outermost."""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -19,23 +20,23 @@ fw = model(pose, betas, trans)
 tv, tj = fw['vertices'].contiguous(), fw['joints'].contiguous()
 h = model._native(dev)
 
-def run(nchunks, stagger_ms=0.0, steps=20):
-    cb = B // nchunks
-    streams = [torch.cuda.Stream() for _ in range(nchunks)]
-    wss = [torch.empty(h.workspace_bytes(cb), dtype=torch.uint8, device=dev) for _ in range(nchunks)]
-    tvs = [tv[i * cb:(i + 1) * cb].contiguous() for i in range(nchunks)]
-    tjs = [tj[i * cb:(i + 1) * cb].contiguous() for i in range(nchunks)]
+def run(nstreams, chunk, steps=10):
+    streams = [torch.cuda.Stream() for _ in range(nstreams)]
+    wss = [torch.empty(h.workspace_bytes(chunk), dtype=torch.uint8, device=dev) for _ in range(nstreams)]
+    nch = B // chunk
     def step():
-        for i, s in enumerate(streams):
-            with torch.cuda.stream(s):
-                fitter.fit(tvs[i], tjs[i], num_iter=3, beta_regularizer=1.0, _workspace=wss[i])
-    for _ in range(3): step()
+        for c in range(nch):
+            s = c % nstreams
+            with torch.cuda.stream(streams[s]):
+                fitter.fit(tv[c * chunk:(c + 1) * chunk], tj[c * chunk:(c + 1) * chunk], num_iter=3,
+                           beta_regularizer=1.0, _workspace=wss[s])
+    for _ in range(2): step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps): step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    print(f'chunks={nchunks}: {dt*1e3:.3f} ms/step  {B/dt:,.0f} fits/s', flush=True)
+    print(f'streams={nstreams} chunk={chunk}: {dt*1e3:.3f} ms/step  {B/dt:,.0f} fits/s', flush=True)
 
-for n in (1, 2, 4, 8):
-    run(n)
+for ns, ch in ((1, 4096), (2, 1024), (4, 1024), (4, 512), (3, 512), (4, 256), (8, 256), (2, 512)):
+    run(ns, ch)
