@@ -54,6 +54,12 @@ typedef struct smplfit_model_desc {
   const int32_t* parents;          /* (J) kinematic parents, parents[0] ignored                */
   const float* J_regressor_post_lbs; /* (J, regressor_num_vertices) or NULL                    */
   int32_t regressor_num_vertices;  /* must equal V for the joints-omitted path                 */
+  /* kid blend shape (BodyFitter(enable_kid=True), pt/bodyfitter.py:52-58; BodyModel.forward's
+   * kid_factor, pt/bodymodel.py:258-295): when enable_kid != 0 the handle carries ONE extra shape
+   * unknown whose vertex / joint directions are kid_shapedir / kid_J_shapedir. */
+  int32_t enable_kid;
+  const float* kid_shapedir;       /* (V,3) or NULL                                            */
+  const float* kid_J_shapedir;     /* (J,3) or NULL                                            */
 } smplfit_model_desc;
 
 enum { SMPLFIT_CREATE_HOST_ONLY = 1 }; /* build tables, upload nothing (no GPU needed)         */
@@ -67,7 +73,8 @@ const char* smplfit_last_error(void);
 const char* smplfit_version(void);
 
 typedef struct smplfit_info {
-  int32_t num_vertices, num_joints, num_betas;
+  int32_t num_vertices, num_joints, num_betas; /* num_betas excludes the kid unknown */
+  int32_t has_kid;
   int32_t padded_vertices;     /* Vp: vertices padded for the kernels                          */
   int32_t num_used_vertices;   /* vertices entering the part sums (pt/bodyfitter.py:109-114)   */
   int32_t skin_width;          /* non-zero skinning weights kept per vertex (4 or 8)           */
@@ -99,26 +106,30 @@ size_t smplfit_workspace_bytes(const smplfit_handle* h, int batch);
  * no warm start.
  *   target_vertices (B,V,3); target_joints (B,J,3) or NULL; vertex_weights (B,V) or NULL;
  *   joint_weights (B,J) or NULL.
- * Outputs: pose_rotvecs (B,3J), shape_betas (B,S), trans (B,3); orientations (B,J,3,3) and
- * relative_orientations (B,J,3,3) (parent^T @ global, pt/bodyfitter.py:523-533) may be NULL.
+ * Outputs: pose_rotvecs (B,3J), shape_betas (B,S), trans (B,3); kid_factor (B) (only for kid
+ * handles, else NULL), orientations (B,J,3,3) and relative_orientations (B,J,3,3) (parent^T @
+ * global, pt/bodyfitter.py:523-533) may be NULL.  kid_regularizer: ridge weight of the kid unknown
+ * (the reference defaults it to beta_regularizer, pt/bodyfitter.py:1235-1237); ignored without kid.
  */
 int smplfit_fit_f32(const smplfit_handle* h, const float* target_vertices,
                     const float* target_joints, const float* vertex_weights,
                     const float* joint_weights, int batch, int num_iter, float beta_regularizer,
-                    float beta_regularizer2, int final_adjust_rots, float* pose_rotvecs,
-                    float* shape_betas, float* trans, float* orientations,
-                    float* relative_orientations, void* workspace, size_t workspace_bytes,
-                    void* hip_stream);
+                    float beta_regularizer2, float kid_regularizer, int final_adjust_rots,
+                    float* pose_rotvecs, float* shape_betas, float* trans, float* kid_factor,
+                    float* orientations, float* relative_orientations, void* workspace,
+                    size_t workspace_bytes, void* hip_stream);
 
 /*
  * BodyModel.forward (pt/bodymodel.py:121-307).  Exactly one of pose_rotvecs (B,3J) /
- * glob_rotmats (B,J,3,3) non-NULL; shape_betas (B,num_betas_given) or NULL; trans (B,3) or NULL.
+ * glob_rotmats (B,J,3,3) non-NULL; shape_betas (B,num_betas_given) or NULL; trans (B,3) or NULL;
+ * kid_factor (B) or NULL (kid handles only).
  * Outputs: vertices (B,V,3) may be NULL (joints only); joints (B,J,3); orientations (B,J,3,3) may
  * be NULL.
  */
 int smplfit_forward_f32(const smplfit_handle* h, const float* pose_rotvecs,
                         const float* glob_rotmats, const float* shape_betas, int num_betas_given,
-                        const float* trans, int batch, float* vertices, float* joints,
+                        const float* trans, const float* kid_factor, int batch, float* vertices,
+                        float* joints,
                         float* orientations, void* workspace, size_t workspace_bytes,
                         void* hip_stream);
 
@@ -133,13 +144,16 @@ int smplfit_part_rotations_f32(const smplfit_handle* h, const float* target_vert
                                void* workspace, size_t workspace_bytes, void* hip_stream);
 
 /* One shape solve (pt/bodyfitter.py:840-1102, _fit_shape -> _fit_shape_gram) for given global
- * rotations on targets that are centred internally exactly as fit() does; trans is returned
- * WITHOUT the mean added back.  vertices_out (B,V,3) / joints_out (B,J,3) may be NULL. */
+ * rotations on targets that are centred internally exactly as fit() does.  add_mean = 0: trans /
+ * vertices / joints stay in the centred frame (stage parity tests); add_mean = 1: the target mean is
+ * added back to trans, i.e. fit_with_known_pose (pt/bodyfitter.py:552-653) once the caller has turned
+ * pose_rotvecs into global rotations.  vertices_out (B,V,3) / joints_out (B,J,3) may be NULL. */
 int smplfit_shape_solve_f32(const smplfit_handle* h, const float* glob_rotmats,
                             const float* target_vertices, const float* target_joints,
                             const float* vertex_weights, const float* joint_weights, int batch,
-                            float beta_regularizer, float beta_regularizer2, float* shape_betas,
-                            float* trans, float* vertices_out, float* joints_out, void* workspace,
+                            float beta_regularizer, float beta_regularizer2, float kid_regularizer,
+                            int add_mean, float* shape_betas, float* trans, float* kid_factor,
+                            float* vertices_out, float* joints_out, void* workspace,
                             size_t workspace_bytes, void* hip_stream);
 
 /* Measurement hook (bench.py's roofline leg): launches ONE kernel of the fit `reps` times on

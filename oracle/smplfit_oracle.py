@@ -115,12 +115,15 @@ class OracleModel:
         self.J_template = f32(md.J_template)
         self.J_shapedirs = f32(md.J_shapedirs)
         self.weights = f32(md.weights)
+        self.kid_shapedir = f32(md.kid_shapedir)
+        self.kid_J_shapedir = f32(md.kid_J_shapedir)
         self.parents = list(md.kintree_parents)
         self.J = md.num_joints
         self.V = md.num_vertices
         self.S = self.shapedirs.shape[2]
 
-    def forward(self, pose_rotvecs=None, shape_betas=None, trans=None, glob_rotmats=None):
+    def forward(self, pose_rotvecs=None, shape_betas=None, trans=None, glob_rotmats=None,
+                kid_factor=None):
         """LBS forward (pt/bodymodel.py:121-307): returns vertices, joints, orientations."""
         dt = self.dtype
         J, par = self.J, self.parents
@@ -138,7 +141,9 @@ class OracleModel:
             rel1 = np.swapaxes(glob[:, par[1:]], -1, -2) @ glob[:, 1:]
         betas = np.zeros((B, 0), dt) if shape_betas is None else np.asarray(shape_betas, dt)
         nb = min(betas.shape[1], self.S)
-        j = self.J_template + np.einsum('jcs,bs->bjc', self.J_shapedirs[:, :, :nb], betas[:, :nb])
+        kid = np.zeros((1,), dt) if kid_factor is None else np.asarray(kid_factor, dt).reshape(-1)
+        j = (self.J_template + np.einsum('jcs,bs->bjc', self.J_shapedirs[:, :, :nb], betas[:, :nb])
+             + self.kid_J_shapedir[None] * kid[:, None, None])
         bones = j[:, 1:] - j[:, par[1:]]
         rot_bones = np.einsum('bjCc,bjc->bjC', glob[:, par[1:]], bones)
         pos = [j[:, 0]]
@@ -151,6 +156,7 @@ class OracleModel:
             self.v_template
             + np.einsum('vcs,bs->bvc', self.shapedirs[:, :, :nb], betas[:, :nb])
             + (feat @ self.posedirs.reshape(self.V * 3, -1).T).reshape(B, self.V, 3)
+            + self.kid_shapedir[None] * kid[:, None, None]
         )
         translations = pos - np.einsum('bjCc,bjc->bjC', glob, j)
         rot_blend = np.einsum('vj,bjk->bvk', self.weights, glob.reshape(B, J, 9)).reshape(
@@ -173,8 +179,9 @@ class OracleModel:
 class OracleFitter:
     """Default-configuration ``BodyFitter`` (no share_beta / scale / kid / warm start)."""
 
-    def __init__(self, model: OracleModel):
+    def __init__(self, model: OracleModel, enable_kid: bool = False):
         m = self.m = model
+        self.enable_kid = enable_kid
         J, par = m.J, m.parents
         self.smpl_family = m.model_name.startswith('smpl')
         # part assignment: dominant skinning weight, SMPL toes -> feet (pt/bodyfitter.py:36-44)
@@ -205,7 +212,15 @@ class OracleFitter:
         for i in range(1, J):
             depth[i] = depth[par[i]] + 1
         self.levels = [[i for i in range(J) if depth[i] == d] for d in range(1, max(depth) + 1)]
-        self.J_ext = np.concatenate([m.J_template[:, :, None], m.J_shapedirs], axis=2)  # (J,3,S+1)
+        # shape directions with the kid blend shape as one more unknown (pt/bodyfitter.py:52-58,
+        # :1139-1149); S_all = S (+1)
+        self.shapedirs = m.shapedirs
+        jsd = m.J_shapedirs
+        if enable_kid:
+            self.shapedirs = np.concatenate([m.shapedirs, m.kid_shapedir[:, :, None]], axis=2)
+            jsd = np.concatenate([m.J_shapedirs, m.kid_J_shapedir[:, :, None]], axis=2)
+        self.S_all = self.shapedirs.shape[2]
+        self.J_ext = np.concatenate([m.J_template[:, :, None], jsd], axis=2)  # (J,3,S_all+1)
         pw = [0] + par[1:]
         self.bone_ext = self.J_ext - self.J_ext[pw]
         self.default_mesh = m.forward(
@@ -304,8 +319,8 @@ class OracleFitter:
         return R
 
     # -- shape solve (pt/bodyfitter.py:840-1102) --------------------------------------------------
-    def fit_shape(self, G, tv, tj, vw, jw, beta_reg, beta_reg2):
-        m, dt, J, S, par = self.m, self.m.dtype, self.m.J, self.m.S, self.m.parents
+    def fit_shape(self, G, tv, tj, vw, jw, beta_reg, beta_reg2, kid_reg=None):
+        m, dt, J, S, par = self.m, self.m.dtype, self.m.J, self.S_all, self.m.parents
         B = tv.shape[0]
         Gpar = np.concatenate([np.broadcast_to(np.eye(3, dtype=dt), (B, 1, 3, 3)), G[:, par[1:]]], 1)
         rel = np.swapaxes(Gpar, -1, -2) @ G
@@ -322,7 +337,7 @@ class OracleFitter:
         Rb = np.einsum('vj,bjk->bvk', m.weights, G.reshape(B, J, 9)).reshape(B, m.V, 3, 3)
         Tb = np.einsum('vj,bjcs->bvcs', m.weights, T)  # (B,V,3,S+1)
         pos = np.einsum('bvCc,bvc->bvC', Rb, v_posed) + Tb[..., 0]
-        jac = np.einsum('bvCc,vcs->bvCs', Rb, m.shapedirs) + Tb[..., 1:]
+        jac = np.einsum('bvCc,vcs->bvCs', Rb, self.shapedirs) + Tb[..., 1:]
         b = tv - pos
         # effective weights (:1018-1028)
         if tj is not None and vw is not None and jw is not None:
@@ -358,17 +373,24 @@ class OracleFitter:
         Ws = np.where(W == 0, 1.0, W)
         gram_c = gram - np.swapaxes(sA, 1, 2) @ sA / Ws
         rhs_c = rhs - np.swapaxes(sA, 1, 2) @ sb / Ws
-        lam = np.concatenate([np.full(2, float(beta_reg2)), np.full(S - 2, float(beta_reg))])
+        n_plain = m.S
+        lam = np.concatenate([np.full(2, float(beta_reg2)), np.full(n_plain - 2, float(beta_reg))])
+        if self.enable_kid:  # kid_regularizer defaults to beta_regularizer (pt/bodyfitter.py:1235-1242)
+            lam = np.concatenate([lam, [float(beta_reg if kid_reg is None else kid_reg)]])
         x = np.linalg.solve(gram_c + np.diag(lam), rhs_c)  # SPD; reference uses Cholesky (:1083-1084)
         trans = (sb / Ws - (sA / Ws) @ x)[..., 0].astype(dt)
         beta = x[..., 0].astype(dt)
         joints = P[..., 0] + np.einsum('bjcs,bs->bjc', P[..., 1:], beta) + trans[:, None]
         verts = pos + np.einsum('bvcs,bs->bvc', jac, beta) + trans[:, None]
-        return dict(shape_betas=beta, trans=trans, joints=joints.astype(dt), vertices=verts.astype(dt),
-                    gram_cen=gram_c, rhs_cen=rhs_c)
+        out = dict(shape_betas=beta[:, :n_plain], trans=trans, joints=joints.astype(dt),
+                   vertices=verts.astype(dt), gram_cen=gram_c, rhs_cen=rhs_c, beta_all=beta)
+        if self.enable_kid:
+            out['kid_factor'] = beta[:, n_plain]
+        return out
 
     # -- dependent refinement, level-batched branch (pt/bodyfitter.py:1418-1544) -------------------
     def fit_global_rotations_dependent(self, tv, tj, rv, rj_true, vw, jw, G, beta, trans):
+        """beta: all shape unknowns (betas + kid when enabled)."""
         m, dt, J, par = self.m, self.m.dtype, self.m.J, self.m.parents
         B = tv.shape[0]
         if tj is None:
@@ -376,7 +398,7 @@ class OracleFitter:
             rj = np.einsum('jv,bvc->bjc', m.J_regressor_post_lbs, rv)
         else:
             rj = rj_true
-        j = m.J_template + np.einsum('jcs,bs->bjc', m.J_shapedirs, beta)
+        j = self.J_ext[None, :, :, 0] + np.einsum('jcs,bs->bjc', self.J_ext[:, :, 1:], beta)
         jpar = np.concatenate([np.zeros((B, 1, 3), dt), j[:, par[1:]]], 1)
         bones = j - jpar
         raw, st, sa, sw = self.part_sums(tv, rv, vw)
@@ -407,7 +429,7 @@ class OracleFitter:
     # -- driver (pt/bodyfitter.py:283-549) ----------------------------------------------------------
     def fit(self, target_vertices, target_joints=None, vertex_weights=None, joint_weights=None,
             num_iter=1, beta_regularizer=1.0, beta_regularizer2=0.0, final_adjust_rots=True,
-            return_stages=False):
+            return_stages=False, kid_regularizer=None):
         m, dt, J, par = self.m, self.m.dtype, self.m.J, self.m.parents
         tv = np.asarray(target_vertices, dt)
         tj = None if target_joints is None else np.asarray(target_joints, dt)
@@ -425,19 +447,19 @@ class OracleFitter:
         G = self.fit_global_rotations(tv, tj, self.default_mesh[None], m.J_template[None], vw, jw)
         stages['glob_rotmats_iter0'] = G.copy()
         for it in range(num_iter - 1):
-            r = self.fit_shape(G, tv, tj, vw, jw, beta_regularizer, beta_regularizer2)
+            r = self.fit_shape(G, tv, tj, vw, jw, beta_regularizer, beta_regularizer2, kid_regularizer)
             if it == 0:
                 stages['gram_cen0'], stages['rhs_cen0'] = r['gram_cen'], r['rhs_cen']
                 stages['shape_betas0'], stages['trans0'] = r['shape_betas'], r['trans']
             rj = r['joints'] if tj is not None else None
             G = self.fit_global_rotations(tv, tj, r['vertices'], rj, vw, jw) @ G
-        r = self.fit_shape(G, tv, tj, vw, jw, beta_regularizer, beta_regularizer2)
+        r = self.fit_shape(G, tv, tj, vw, jw, beta_regularizer, beta_regularizer2, kid_regularizer)
         if num_iter == 1:
             stages['gram_cen0'], stages['rhs_cen0'] = r['gram_cen'], r['rhs_cen']
             stages['shape_betas0'], stages['trans0'] = r['shape_betas'], r['trans']
         if final_adjust_rots:
             G = self.fit_global_rotations_dependent(
-                tv, tj, r['vertices'], r['joints'], vw, jw, G, r['shape_betas'], r['trans']
+                tv, tj, r['vertices'], r['joints'], vw, jw, G, r['beta_all'], r['trans']
             )
         Gpar = np.concatenate([np.broadcast_to(np.eye(3, dtype=dt), (B, 1, 3, 3)), G[:, par[1:]]], 1)
         rel = np.swapaxes(Gpar, -1, -2) @ G
@@ -448,6 +470,35 @@ class OracleFitter:
             orientations=G,
             relative_orientations=rel,
         )
+        if self.enable_kid:
+            out['kid_factor'] = r['kid_factor']
         if return_stages:
             out['stages'] = stages
+        return out
+
+    # -- shape + translation for a known pose (pt/bodyfitter.py:552-653) -----------------------------
+    def fit_with_known_pose(self, pose_rotvecs, target_vertices, target_joints=None,
+                            vertex_weights=None, joint_weights=None, beta_regularizer=1.0,
+                            beta_regularizer2=0.0, kid_regularizer=None):
+        m, dt, J, par = self.m, self.m.dtype, self.m.J, self.m.parents
+        tv = np.asarray(target_vertices, dt)
+        tj = None if target_joints is None else np.asarray(target_joints, dt)
+        vw = None if vertex_weights is None else np.asarray(vertex_weights, dt)
+        jw = None if joint_weights is None else np.asarray(joint_weights, dt)
+        B = tv.shape[0]
+        if tj is None:
+            mean = tv.mean(1)
+            tv = tv - mean[:, None]
+        else:
+            mean = np.concatenate([tv, tj], 1).mean(1)
+            tv, tj = tv - mean[:, None], tj - mean[:, None]
+        rel = rotvec2mat(np.asarray(pose_rotvecs, dt).reshape(B, J, 3))
+        glob = [rel[:, 0]]
+        for i in range(1, J):
+            glob.append(glob[par[i]] @ rel[:, i])
+        G = np.stack(glob, 1)
+        r = self.fit_shape(G, tv, tj, vw, jw, beta_regularizer, beta_regularizer2, kid_regularizer)
+        out = dict(shape_betas=r['shape_betas'], trans=(r['trans'] + mean).astype(dt), orientations=G)
+        if self.enable_kid:
+            out['kid_factor'] = r['kid_factor']
         return out

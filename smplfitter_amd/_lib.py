@@ -55,6 +55,9 @@ class ModelDesc(C.Structure):
         ('parents', _ip),
         ('J_regressor_post_lbs', _fp),
         ('regressor_num_vertices', C.c_int32),
+        ('enable_kid', C.c_int32),
+        ('kid_shapedir', _fp),
+        ('kid_J_shapedir', _fp),
     ]
 
 
@@ -62,7 +65,7 @@ class Info(C.Structure):
     _fields_ = [
         (n, C.c_int32)
         for n in (
-            'num_vertices', 'num_joints', 'num_betas', 'padded_vertices', 'num_used_vertices',
+            'num_vertices', 'num_joints', 'num_betas', 'has_kid', 'padded_vertices', 'num_used_vertices',
             'skin_width', 'num_segments', 'num_fk_levels', 'adj_last_level', 'has_device',
         )
     ]  # fmt: skip
@@ -104,13 +107,13 @@ def load():
     lib.smplfit_get_table.restype = i32
     lib.smplfit_workspace_bytes.argtypes = [vp, i32]
     lib.smplfit_workspace_bytes.restype = sz
-    lib.smplfit_fit_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp, vp, vp, vp, vp, sz, vp]
+    lib.smplfit_fit_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.smplfit_fit_f32.restype = i32
-    lib.smplfit_forward_f32.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, sz, vp]
+    lib.smplfit_forward_f32.argtypes = [vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, sz, vp]
     lib.smplfit_forward_f32.restype = i32
     lib.smplfit_part_rotations_f32.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, sz, vp]
     lib.smplfit_part_rotations_f32.restype = i32
-    lib.smplfit_shape_solve_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, vp, vp, sz, vp]
+    lib.smplfit_shape_solve_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, i32, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.smplfit_shape_solve_f32.restype = i32
     lib.smplfit_time_kernel_f32.argtypes = [vp, i32, i32, i32, vp, sz, vp, C.POINTER(C.c_float)]
     lib.smplfit_time_kernel_f32.restype = i32
@@ -131,7 +134,7 @@ def check(status: int):
 
 
 def make_desc(v_template, shapedirs, posedirs, weights, J_template, J_shapedirs, parents,
-              J_regressor_post_lbs=None, is_smpl_family=True):
+              J_regressor_post_lbs=None, is_smpl_family=True, kid_shapedir=None, kid_J_shapedir=None):
     """Build a ``ModelDesc`` from numpy arrays; returns (desc, keepalive list)."""
     f32c = lambda a: np.ascontiguousarray(np.asarray(a), dtype=np.float32)  # noqa: E731
     arrs = dict(
@@ -160,6 +163,17 @@ def make_desc(v_template, shapedirs, posedirs, weights, J_template, J_shapedirs,
     else:
         d.J_regressor_post_lbs = None
         d.regressor_num_vertices = 0
+    if kid_shapedir is not None:
+        ks, kj = f32c(kid_shapedir), f32c(kid_J_shapedir)
+        assert ks.shape == (V, 3) and kj.shape == (J, 3)
+        d.enable_kid = 1
+        d.kid_shapedir = ks.ctypes.data_as(_fp)
+        d.kid_J_shapedir = kj.ctypes.data_as(_fp)
+        keep += [ks, kj]
+    else:
+        d.enable_kid = 0
+        d.kid_shapedir = None
+        d.kid_J_shapedir = None
     return d, keep
 
 

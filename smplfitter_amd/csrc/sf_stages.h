@@ -47,6 +47,7 @@ SF_HD F4 ld4(const float* p) { return *reinterpret_cast<const F4*>(p); }
 // Tables a joint-level stage reads (device or host pointers).
 struct JointTabs {
   int J, S, num_levels, adj_last_level, P, Kp;
+  int n_kid;  // 1: the last of the S shape unknowns is the kid blend shape
   const int32_t *parents, *fk_js, *fk_level_start, *cas_start, *cas_flat, *part_type, *toe_src;
   const int32_t *adj_level_start, *adj_parts;
   const float *j_ext, *bone_ext;  // (J,3,S+1)
@@ -309,7 +310,7 @@ SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
 template <class Ctx>
 SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const double* gramv,
                        const float* gramj, const float* pext, const float* jd, const float* mb,
-                       float beta_reg, float beta_reg2, float* beta_out, float* trans_out,
+                       float beta_reg, float beta_reg2, float kid_reg, float* beta_out, float* trans_out,
                        float* rjoints_out, float* jb_out) {
   const int J = tb.J, S = tb.S, S1 = S + 1;
   const int NG = ne_ng(S), NE = ne_size(S);
@@ -340,7 +341,8 @@ SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const doubl
     if (j <= i) {  // lower triangle: M[i][j] = G[j][i] - sum_c SA[c][i] SA[c][j] / W (+ lambda)
       double g = sum[ne_g(S, j, i)];
       g -= (SA[i] * SA[j] + SA[S + i] * SA[S + j] + SA[2 * S + i] * SA[2 * S + j]) / W;
-      if (i == j) g += (double)(i < 2 ? beta_reg2 : beta_reg);  // (:1064-1071)
+      if (i == j)  // (:1064-1071; kid unknown :1235-1242)
+        g += (double)(i >= S - tb.n_kid ? kid_reg : (i < 2 ? beta_reg2 : beta_reg));
       M[i * S + j] = g;
     }
   }
@@ -413,7 +415,7 @@ SF_HD void refine_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, co
                         const float* tj_in, const float* rj_joint_term, const float* rj_true,
                         const float* jw, const float* Gprev, const float* beta, const float* trans,
                         const float* mean, bool final_adjust, float* pose_out, float* beta_out,
-                        float* trans_out, float* orient_out, float* rel_out) {
+                        float* trans_out, float* kid_out, float* orient_out, float* rel_out) {
   const int J = tb.J, S = tb.S, S1 = S + 1;
   SF_FOR(k, J * 9) {
     sh.G[k] = Gprev[k];
@@ -491,7 +493,8 @@ SF_HD void refine_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, co
     if (rel_out)
       for (int k = 0; k < 9; ++k) rel_out[j * 9 + k] = rel[k];
   }
-  SF_FOR(i, S) beta_out[i] = beta[i];
+  SF_FOR(i, S - tb.n_kid) beta_out[i] = beta[i];
+  if (tb.n_kid && kid_out && cx.lane == 0) kid_out[0] = beta[S - 1];
   SF_FOR(c, 3) trans_out[c] = trans[c] + mean[c];  // (:519)
 }
 
@@ -503,7 +506,7 @@ SF_HD void refine_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, co
 template <class Ctx>
 SF_HD void forward_joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh,
                                const float* pose_rotvecs, const float* glob_in, const float* betas,
-                               int nb, const float* trans, float* rp_out, float* jd_out,
+                               int nb, const float* kid, const float* trans, float* rp_out, float* jd_out,
                                float* joints_out, float* orient_out) {
   const int J = tb.J, S = tb.S, S1 = S + 1;
   if (glob_in) {
@@ -538,6 +541,7 @@ SF_HD void forward_joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch&
   SF_FOR(k, J * 3) {  // joints from betas (bodymodel.py:258-264)
     float acc = 0.f;
     for (int s = 0; s < nb; ++s) acc += tb.j_ext[k * S1 + 1 + s] * betas[s];
+    if (kid && tb.n_kid) acc += tb.j_ext[k * S1 + S] * kid[0];  // kid_J_shapedir (bodymodel.py:263)
     sh.aux[k] = tb.j_ext[k * S1] + acc;
   }
   SF_FOR(j, J) {  // pose feature (bodymodel.py:244-251, :286)

@@ -17,7 +17,23 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
     return "smplfit_create: null model array";
   if (d.num_vertices <= 0 || d.num_joints <= 1 || d.num_betas <= 0)
     return "smplfit_create: bad model dimensions";
-  const int V = d.num_vertices, J = d.num_joints, S = d.num_betas;
+  const int V = d.num_vertices, J = d.num_joints;
+  const int n_kid = d.enable_kid ? 1 : 0;
+  if (n_kid && (!d.kid_shapedir || !d.kid_J_shapedir))
+    return "smplfit_create: enable_kid without kid_shapedir / kid_J_shapedir";
+  const int S = d.num_betas + n_kid;  // the kid blend shape is one more shape direction
+  // shape directions with the kid column appended (bodyfitter.py:52-58, :1139-1149)
+  std::vector<float> shapedirs_ext((size_t)V * 3 * S), jshapedirs_ext((size_t)J * 3 * S);
+  for (size_t r = 0; r < (size_t)V * 3; ++r) {
+    for (int s2 = 0; s2 < d.num_betas; ++s2) shapedirs_ext[r * S + s2] = d.shapedirs[r * d.num_betas + s2];
+    if (n_kid) shapedirs_ext[r * S + S - 1] = d.kid_shapedir[r];
+  }
+  for (size_t r = 0; r < (size_t)J * 3; ++r) {
+    for (int s2 = 0; s2 < d.num_betas; ++s2) jshapedirs_ext[r * S + s2] = d.J_shapedirs[r * d.num_betas + s2];
+    if (n_kid) jshapedirs_ext[r * S + S - 1] = d.kid_J_shapedir[r];
+  }
+  const float* const shapedirs = shapedirs_ext.data();
+  const float* const J_shapedirs = jshapedirs_ext.data();
   if (J > kMaxJoints) {
     *unsupported = true;
     return "smplfit_create: more than 64 joints is not supported";
@@ -27,6 +43,7 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
     return "smplfit_create: num_betas < 2 is not supported";
   }
   t.V = V; t.J = J; t.S = S; t.P = 9 * (J - 1);
+  t.n_kid = n_kid;
   t.Vp = round_up(V, kVertexPad);
   t.Kp = round_up(t.P, kGemmKPad);
   t.smpl_family = d.is_smpl_family != 0;
@@ -195,7 +212,7 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
       }
       t.dm[(size_t)c * Vp + i] = wsum * acc;
       for (int s = 0; s < S; ++s)
-        t.sd[(size_t)(c * S + s) * Vp + i] = d.shapedirs[((size_t)v * 3 + c) * S + s];
+        t.sd[(size_t)(c * S + s) * Vp + i] = shapedirs[((size_t)v * 3 + c) * S + s];
     }
   }
   t.vtN = t.vt;
@@ -234,7 +251,7 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
     for (int c = 0; c < 3; ++c) {
       t.j_ext[((size_t)j * 3 + c) * S1] = d.J_template[j * 3 + c];
       for (int s = 0; s < S; ++s)
-        t.j_ext[((size_t)j * 3 + c) * S1 + 1 + s] = d.J_shapedirs[((size_t)j * 3 + c) * S + s];
+        t.j_ext[((size_t)j * 3 + c) * S1 + 1 + s] = J_shapedirs[((size_t)j * 3 + c) * S + s];
     }
   for (int j = 0; j < J; ++j)
     for (int k = 0; k < 3 * S1; ++k)
@@ -262,7 +279,7 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
         const double w = d.weights[(size_t)v * J + j];
         if (w == 0.0) continue;
         cw[j] += w;
-        for (int k = 0; k < 3 * S; ++k) cs[(size_t)j * 3 * S + k] += w * d.shapedirs[(size_t)v * 3 * S + k];
+        for (int k = 0; k < 3 * S; ++k) cs[(size_t)j * 3 * S + k] += w * shapedirs[(size_t)v * 3 * S + k];
       }
     t.cs_joint.assign(cs.size(), 0.f);
     t.cw_joint.assign(J, 0.f);
@@ -296,7 +313,7 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
     std::vector<double> outer((size_t)9 * SS);
     for (int v = 0; v < V; ++v) {
       const float* w = d.weights + (size_t)v * J;
-      const float* sv = d.shapedirs + (size_t)v * 3 * S;  // [a][i]
+      const float* sv = shapedirs + (size_t)v * 3 * S;  // [a][i]
       bool have_outer = false;
       for (int j = 0; j < J; ++j) {
         if (w[j] == 0.f) continue;

@@ -29,7 +29,8 @@ struct Segment {
 };
 
 struct HostTables {
-  int V = 0, J = 0, S = 0, P = 0;
+  int V = 0, J = 0, S = 0, P = 0;  // S counts every shape unknown: betas + kid
+  int n_kid = 0;                   // 1 if the last unknown is the kid blend shape
   int Vp = 0, Kp = 0, KW = 4;
   bool smpl_family = false;
   bool has_regressor = false;

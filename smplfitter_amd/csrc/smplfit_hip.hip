@@ -831,14 +831,14 @@ __global__ __launch_bounds__(64) void k_pair_gram(DevModel m, Workspace ws) {
 // K4: solve.  grid B, block 64.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_shape_solve(DevModel m, Workspace ws, float beta_reg,
-                                                    float beta_reg2, int pair_form) {
+                                                    float beta_reg2, float kid_reg, int pair_form) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, J = m.J, S = m.S;
   DevCtx cx{(int)threadIdx.x, 64};
   const int NE1 = sf::ne_size(S) + 1;
   sf::solve_stage(cx, m.jt, smem, ws.gramv + (size_t)b * NE1, ws.gramj + (size_t)b * NE1,
                   ws.pext + (size_t)b * J * 3 * (S + 1), ws.jd + (size_t)b * J * sf::jd_stride(S),
-                  pair_form ? ws.mbj + (size_t)b * J * 3 : nullptr, beta_reg, beta_reg2,
+                  pair_form ? ws.mbj + (size_t)b * J * 3 : nullptr, beta_reg, beta_reg2, kid_reg,
                   ws.beta + (size_t)b * S, ws.trans + (size_t)b * 3, ws.rjoints + (size_t)b * J * 3,
                   ws.jb + (size_t)b * J * 4);
 }
@@ -855,6 +855,7 @@ template <int S, int KW, bool WEIGHTED, int MODE, bool SOLVE>
 __global__ __launch_bounds__(256) void k_lbs_partsum(DevModel m, Workspace ws, int B, int nb,
                                                      const float* __restrict__ beta_in,
                                                      const float* __restrict__ trans_in,
+                                                     const float* __restrict__ kid_in,
                                                      float* __restrict__ out, float beta_reg,
                                                      float beta_reg2) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -886,13 +887,17 @@ __global__ __launch_bounds__(256) void k_lbs_partsum(DevModel m, Workspace ws, i
     if (lane < 32) sbeta[lane] = 0.f;
     sf::solve_stage(cx, m.jt, strans + 4, ws.gramv + (size_t)b * NE1, ws.gramj + (size_t)b * NE1,
                     ws.pext + (size_t)b * J * 3 * (S + 1), ws.jd + (size_t)b * J * STRIDE, nullptr,
-                    beta_reg, beta_reg2, sbeta, strans, ws.rjoints + (size_t)b * J * 3, jb);
+                    beta_reg, beta_reg2, beta_reg, sbeta, strans, ws.rjoints + (size_t)b * J * 3, jb);
     __syncthreads();
     if (lane < S) ws.beta[(size_t)b * S + lane] = sbeta[lane];
     if (lane < 3) ws.trans[(size_t)b * 3 + lane] = strans[lane];
   } else {
     for (int k = lane; k < J * 4; k += 64) jb[k] = ws.jb[(size_t)b * J * 4 + k];
-    if (lane < S) sbeta[lane] = (beta_in && lane < nb) ? beta_in[(size_t)b * nb + lane] : 0.f;
+    if (lane < S) {
+      float v = (beta_in && lane < nb) ? beta_in[(size_t)b * nb + lane] : 0.f;
+      if (kid_in && m.jt.n_kid && lane == S - 1) v = kid_in[b];
+      sbeta[lane] = v;
+    }
     if (lane < 3) strans[lane] = trans_in ? trans_in[(size_t)b * 3 + lane] : 0.f;
   }
   // MODE 2 walks the dense tiles (every slot), the other modes the part-aligned segments
@@ -1032,7 +1037,7 @@ struct RefineArgs {
   const float* rj_term;   // (B,J,3) reference joints of the joint term
   const float* jw;        // (B,J) or null
   int final_adjust;
-  float *pose, *betas, *trans, *orient, *rel;
+  float *pose, *betas, *trans, *kid, *orient, *rel;
 };
 
 __global__ __launch_bounds__(64) void k_refine_epilogue(DevModel m, RefineArgs a, Workspace ws) {
@@ -1044,8 +1049,9 @@ __global__ __launch_bounds__(64) void k_refine_epilogue(DevModel m, RefineArgs a
                    a.rj_term + (size_t)b * J * 3, ws.rjoints + (size_t)b * J * 3,
                    a.jw ? a.jw + (size_t)b * J : nullptr, ws.G + (size_t)b * J * 9,
                    ws.beta + (size_t)b * S, ws.trans + (size_t)b * 3, ws.mean + (size_t)b * 3,
-                   a.final_adjust != 0, a.pose + (size_t)b * J * 3, a.betas + (size_t)b * S,
-                   a.trans + (size_t)b * 3, a.orient ? a.orient + (size_t)b * J * 9 : nullptr,
+                   a.final_adjust != 0, a.pose + (size_t)b * J * 3,
+                   a.betas + (size_t)b * (S - m.jt.n_kid), a.trans + (size_t)b * 3,
+                   a.kid ? a.kid + b : nullptr, a.orient ? a.orient + (size_t)b * J * 9 : nullptr,
                    a.rel ? a.rel + (size_t)b * J * 9 : nullptr);
 }
 
@@ -1053,7 +1059,7 @@ __global__ __launch_bounds__(64) void k_refine_epilogue(DevModel m, RefineArgs a
 // forward: joint prologue.  grid B, block 64.
 // ------------------------------------------------------------------------------------------------
 struct ForwardArgs {
-  const float *pose, *glob, *betas, *trans;
+  const float *pose, *glob, *betas, *trans, *kid;
   int nb;
   float *joints, *orient;
 };
@@ -1067,13 +1073,26 @@ __global__ __launch_bounds__(64) void k_forward_joint(DevModel m, ForwardArgs a,
   sf::forward_joint_stage(cx, m.jt, sh, a.pose ? a.pose + (size_t)b * J * 3 : nullptr,
                           a.glob ? a.glob + (size_t)b * J * 9 : nullptr,
                           a.betas ? a.betas + (size_t)b * a.nb : nullptr, a.betas ? a.nb : 0,
-                          a.trans ? a.trans + (size_t)b * 3 : nullptr, ws.rp + (size_t)b * m.Kp, jd,
+                          a.kid ? a.kid + b : nullptr, a.trans ? a.trans + (size_t)b * 3 : nullptr,
+                          ws.rp + (size_t)b * m.Kp, jd,
                           a.joints + (size_t)b * J * 3,
                           a.orient ? a.orient + (size_t)b * J * 9 : nullptr);
   __syncthreads();
   // skinning translations for the vertex kernel
   for (int k = threadIdx.x; k < J * 3; k += 64)
     ws.jb[(size_t)b * J * 4 + (k / 3) * 4 + k % 3] = jd[(k / 3) * sf::jd_stride(S) + 9 + k % 3];
+}
+
+// betas / kid / trans of the last solve to the caller's arrays (shape-solve entry point)
+__global__ void k_emit_solution(Workspace ws, int B, int S, int n_kid, int add_mean,
+                                float* __restrict__ betas, float* __restrict__ trans,
+                                float* __restrict__ kid) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  for (int s = 0; s < S - n_kid; ++s) betas[(size_t)b * (S - n_kid) + s] = ws.beta[(size_t)b * S + s];
+  if (n_kid && kid) kid[b] = ws.beta[(size_t)b * S + S - 1];
+  for (int c = 0; c < 3; ++c)
+    trans[b * 3 + c] = ws.trans[b * 3 + c] + (add_mean ? ws.mean[b * 3 + c] : 0.f);
 }
 
 // scatter G given by the caller into the workspace (shape-solve entry point)
@@ -1121,17 +1140,17 @@ int launch_shape_accum(const DevModel& d, const Workspace& ws, int B, bool weigh
 template <int S, int KW, int MODE, bool SOLVE>
 void launch_lbs(const DevModel& d, const Workspace& ws, int B, bool weighted, int nb,
                 const float* beta, const float* trans, float* out, float beta_reg, float beta_reg2,
-                hipStream_t st) {
+                hipStream_t st, const float* kid = nullptr) {
   const size_t per_wave =
       ((size_t)d.J * sf::jd_stride(S) + d.J * 4 + 36 + (SOLVE ? sf::solve_scratch_floats(S) : 0) + 3) / 4 * 4;
   const size_t lds = (kNW * per_wave + 2 * 64 * sf::cpack_stride(S, KW)) * 4;
   const dim3 grid((B + kNW - 1) / kNW);
   if (weighted)
     hipLaunchKernelGGL((k_lbs_partsum<S, KW, true, MODE, SOLVE>), grid, dim3(256), lds, st, d, ws, B,
-                       nb, beta, trans, out, beta_reg, beta_reg2);
+                       nb, beta, trans, kid, out, beta_reg, beta_reg2);
   else
     hipLaunchKernelGGL((k_lbs_partsum<S, KW, false, MODE, SOLVE>), grid, dim3(256), lds, st, d, ws, B,
-                       nb, beta, trans, out, beta_reg, beta_reg2);
+                       nb, beta, trans, kid, out, beta_reg, beta_reg2);
   if (MODE == 1)
     hipLaunchKernelGGL((k_lbs_rest<S, KW>), dim3(B), dim3(256),
                        ((size_t)d.J * sf::jd_stride(S) + d.J * 4) * 4, st, d, ws);
@@ -1169,8 +1188,11 @@ void launch_center_sort(const DevModel& d, const float* tv, const float* tj, con
     else if ((d).S == 10 && (d).KW == 8) { CALL(10, 8); }                      \
     else if ((d).S == 16 && (d).KW == 4) { CALL(16, 4); }                      \
     else if ((d).S == 16 && (d).KW == 8) { CALL(16, 8); }                      \
+    else if ((d).S == 11 && (d).KW == 4) { CALL(11, 4); }                      \
+    else if ((d).S == 11 && (d).KW == 8) { CALL(11, 8); }                      \
+    else if ((d).S == 17 && (d).KW == 4) { CALL(17, 4); }                      \
     else return fail(SMPLFIT_ERR_UNSUPPORTED,                                  \
-                     "num_betas must be 10 or 16 for the HIP kernels");        \
+                     "num_betas must be 10 or 16 (+1 with the kid blend shape)"); \
   } while (0)
 
 int check_common(const smplfit_handle* h, int batch, void* workspace, size_t workspace_bytes) {
@@ -1218,14 +1240,14 @@ int post_launch_check() {
 // Shared driver of fit / part_rotations / shape_solve.
 struct FitOptions {
   int num_iter;
-  float beta_reg, beta_reg2;
+  float beta_reg, beta_reg2, kid_reg;
   int final_adjust;
   int rotations_only;  // stop after the first rotation pass, write G to `orient`
 };
 
 int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const float* vw,
             const float* jw, int B, const FitOptions& o, float* pose, float* betas, float* trans,
-            float* orient, float* rel, const Workspace& ws, hipStream_t st) {
+            float* kid, float* orient, float* rel, const Workspace& ws, hipStream_t st) {
   const DevModel& d = h->d;
   const bool joints = tj != nullptr;
   if (!joints && !h->t.has_regressor)
@@ -1272,7 +1294,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     // K4 stays its own launch: fused into the prologue of the LBS kernel (template flag SOLVE) its
     // ~40 serial barriers stall all four waves of the workgroup and the kernel ran 230 us longer
     hipLaunchKernelGGL(k_shape_solve, dim3(B), dim3(64), solve_lds(d), st, d, ws, o.beta_reg,
-                       o.beta_reg2, (!eff_v && use_pair_form()) ? 1 : 0);
+                       o.beta_reg2, o.kid_reg, (!eff_v && use_pair_form()) ? 1 : 0);
     const bool last = it + 1 == o.num_iter;
     if (last && !o.final_adjust) break;  // nothing consumes the re-evaluated mesh
     if (joints) {
@@ -1301,6 +1323,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   ra.pose = pose;
   ra.betas = betas;
   ra.trans = trans;
+  ra.kid = kid;
   ra.orient = orient;
   ra.rel = rel;
   hipLaunchKernelGGL(k_refine_epilogue, dim3(B), dim3(64), joint_lds(d, 1), st, d, ra, ws);
@@ -1403,6 +1426,7 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
   sf::JointTabs& jt = d.jt;
   jt.J = t.J; jt.S = t.S; jt.num_levels = t.num_levels(); jt.adj_last_level = t.adj_last_level;
   jt.P = t.P; jt.Kp = t.Kp;
+  jt.n_kid = t.n_kid;
   up(t.parents, &jt.parents);
   up(t.fk_js, &jt.fk_js);
   up(t.fk_level_start, &jt.fk_level_start);
@@ -1444,7 +1468,8 @@ int smplfit_get_info(const smplfit_handle* h, smplfit_info* info) {
   const sf::HostTables& t = h->t;
   info->num_vertices = t.V;
   info->num_joints = t.J;
-  info->num_betas = t.S;
+  info->num_betas = t.S - t.n_kid;
+  info->has_kid = t.n_kid;
   info->padded_vertices = t.Vp;
   info->num_used_vertices = t.n_used;
   info->skin_width = t.KW;
@@ -1491,10 +1516,10 @@ size_t smplfit_workspace_bytes(const smplfit_handle* h, int batch) {
 int smplfit_fit_f32(const smplfit_handle* h, const float* target_vertices,
                     const float* target_joints, const float* vertex_weights,
                     const float* joint_weights, int batch, int num_iter, float beta_regularizer,
-                    float beta_regularizer2, int final_adjust_rots, float* pose_rotvecs,
-                    float* shape_betas, float* trans, float* orientations,
-                    float* relative_orientations, void* workspace, size_t workspace_bytes,
-                    void* hip_stream) {
+                    float beta_regularizer2, float kid_regularizer, int final_adjust_rots,
+                    float* pose_rotvecs, float* shape_betas, float* trans, float* kid_factor,
+                    float* orientations, float* relative_orientations, void* workspace,
+                    size_t workspace_bytes, void* hip_stream) {
   int rc = check_common(h, batch, workspace, workspace_bytes);
   if (rc) return rc;
   if (!target_vertices || !pose_rotvecs || !shape_betas || !trans)
@@ -1502,9 +1527,10 @@ int smplfit_fit_f32(const smplfit_handle* h, const float* target_vertices,
   if (num_iter < 1) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_f32: num_iter must be >= 1");
   Workspace ws;
   carve(h->t, batch, (char*)workspace, &ws);
-  FitOptions o{num_iter, beta_regularizer, beta_regularizer2, final_adjust_rots ? 1 : 0, 0};
+  FitOptions o{num_iter, beta_regularizer, beta_regularizer2, kid_regularizer,
+               final_adjust_rots ? 1 : 0, 0};
   return run_fit(h, target_vertices, target_joints, vertex_weights, joint_weights, batch, o,
-                 pose_rotvecs, shape_betas, trans, orientations, relative_orientations, ws,
+                 pose_rotvecs, shape_betas, trans, kid_factor, orientations, relative_orientations, ws,
                  (hipStream_t)hip_stream);
 }
 
@@ -1518,15 +1544,15 @@ int smplfit_part_rotations_f32(const smplfit_handle* h, const float* target_vert
     return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_part_rotations_f32: null pointer");
   Workspace ws;
   carve(h->t, batch, (char*)workspace, &ws);
-  FitOptions o{1, 0.f, 0.f, 0, 1};
+  FitOptions o{1, 0.f, 0.f, 0.f, 0, 1};
   return run_fit(h, target_vertices, target_joints, vertex_weights, joint_weights, batch, o, nullptr,
-                 nullptr, nullptr, glob_rotmats, nullptr, ws, (hipStream_t)hip_stream);
+                 nullptr, nullptr, nullptr, glob_rotmats, nullptr, ws, (hipStream_t)hip_stream);
 }
 
 int smplfit_forward_f32(const smplfit_handle* h, const float* pose_rotvecs,
                         const float* glob_rotmats, const float* shape_betas, int num_betas_given,
-                        const float* trans, int batch, float* vertices, float* joints,
-                        float* orientations, void* workspace, size_t workspace_bytes,
+                        const float* trans, const float* kid_factor, int batch, float* vertices,
+                        float* joints, float* orientations, void* workspace, size_t workspace_bytes,
                         void* hip_stream) {
   int rc = check_common(h, batch, workspace, workspace_bytes);
   if (rc) return rc;
@@ -1541,8 +1567,11 @@ int smplfit_forward_f32(const smplfit_handle* h, const float* pose_rotvecs,
   fa.pose = pose_rotvecs;
   fa.glob = glob_rotmats;
   fa.betas = shape_betas;
-  fa.nb = shape_betas ? std::min(num_betas_given, d.S) : 0;
-  if (shape_betas && num_betas_given > d.S)
+  fa.nb = shape_betas ? std::min(num_betas_given, d.S - d.jt.n_kid) : 0;
+  if (kid_factor && !d.jt.n_kid)
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_forward_f32: kid_factor given to a handle without kid");
+  fa.kid = kid_factor;
+  if (shape_betas && num_betas_given > d.S - d.jt.n_kid)
     return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_forward_f32: more betas than the model holds; slice first");
   fa.trans = trans;
   fa.joints = joints;
@@ -1551,7 +1580,7 @@ int smplfit_forward_f32(const smplfit_handle* h, const float* pose_rotvecs,
   if (vertices) {
     launch_gemm(d, ws, batch, st);
 #define SF_CALL_LBS(S_, KW_) \
-  launch_lbs<S_, KW_, 2, false>(d, ws, batch, false, fa.nb, shape_betas, trans, vertices, 0.f, 0.f, st)
+  launch_lbs<S_, KW_, 2, false>(d, ws, batch, false, fa.nb, shape_betas, trans, vertices, 0.f, 0.f, st, kid_factor)
     SF_DISPATCH_SKW(d, SF_CALL_LBS);
 #undef SF_CALL_LBS
   }
@@ -1561,8 +1590,9 @@ int smplfit_forward_f32(const smplfit_handle* h, const float* pose_rotvecs,
 int smplfit_shape_solve_f32(const smplfit_handle* h, const float* glob_rotmats,
                             const float* target_vertices, const float* target_joints,
                             const float* vertex_weights, const float* joint_weights, int batch,
-                            float beta_regularizer, float beta_regularizer2, float* shape_betas,
-                            float* trans, float* vertices_out, float* joints_out, void* workspace,
+                            float beta_regularizer, float beta_regularizer2, float kid_regularizer,
+                            int add_mean, float* shape_betas, float* trans, float* kid_factor,
+                            float* vertices_out, float* joints_out, void* workspace,
                             size_t workspace_bytes, void* hip_stream) {
   int rc = check_common(h, batch, workspace, workspace_bytes);
   if (rc) return rc;
@@ -1594,9 +1624,9 @@ int smplfit_shape_solve_f32(const smplfit_handle* h, const float* glob_rotmats,
   SF_DISPATCH_SKW(d, SF_CALL_ACCUM);
 #undef SF_CALL_ACCUM
   hipLaunchKernelGGL(k_shape_solve, dim3(batch), dim3(64), solve_lds(d), st, d, ws, beta_regularizer,
-                     beta_regularizer2, (!eff_v && use_pair_form()) ? 1 : 0);
-  hipLaunchKernelGGL(k_copy, dim3(64), dim3(256), 0, st, ws.beta, shape_betas, (size_t)batch * d.S);
-  hipLaunchKernelGGL(k_copy, dim3(64), dim3(256), 0, st, ws.trans, trans, (size_t)batch * 3);
+                     beta_regularizer2, kid_regularizer, (!eff_v && use_pair_form()) ? 1 : 0);
+  hipLaunchKernelGGL(k_emit_solution, dim3((batch + 255) / 256), dim3(256), 0, st, ws, batch, d.S,
+                     d.jt.n_kid, add_mean, shape_betas, trans, kid_factor);
   if (joints_out)
     hipLaunchKernelGGL(k_copy, dim3(64), dim3(256), 0, st, ws.rjoints, joints_out,
                        (size_t)batch * d.J * 3);
@@ -1632,7 +1662,7 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
         return 0;
       }
       case SMPLFIT_KERNEL_SHAPE_SOLVE:
-        hipLaunchKernelGGL(k_shape_solve, dim3(batch), dim3(64), solve_lds(d), st, d, ws, 1.0f, 0.0f,
+        hipLaunchKernelGGL(k_shape_solve, dim3(batch), dim3(64), solve_lds(d), st, d, ws, 1.0f, 0.0f, 1.0f,
                            use_pair_form() ? 1 : 0);
         return 0;
       case SMPLFIT_KERNEL_LBS_PARTSUM: {

@@ -21,8 +21,8 @@ class BodyFitter(nn.Module):
 
     Parameters:
         body_model: the :class:`BodyModel` to fit.
-        enable_kid: accepted for signature compatibility; the kid blend shape is not implemented
-            by the HIP kernels (``fit`` raises ``NotImplementedError`` when it is set).
+        enable_kid: adds the kid blend shape (AGORA) as one more shape unknown
+            (reference pt/bodyfitter.py:52-58); results then carry ``kid_factor``.
     """
 
     def __init__(self, body_model: BodyModel, enable_kid: bool = False):
@@ -37,8 +37,6 @@ class BodyFitter(nn.Module):
         if scale_target and scale_fit:  # same check, same message as pt/bodyfitter.py:858-859
             raise ValueError('Only one of estim_scale_target and estim_scale_fit can be True')
         unsupported = []
-        if self.enable_kid:
-            unsupported.append('enable_kid')
         if share_beta:
             unsupported.append('share_beta')
         if scale_target or scale_fit:
@@ -101,26 +99,68 @@ class BodyFitter(nn.Module):
         trans = torch.empty((B, 3), dtype=torch.float32, device=device)
         orient = torch.empty((B, J, 3, 3), dtype=torch.float32, device=device)
         rel = torch.empty((B, J, 3, 3), dtype=torch.float32, device=device)
+        kid = torch.empty((B,), dtype=torch.float32, device=device) if self.enable_kid else None
+        # the reference defaults the kid ridge weight to beta_regularizer (pt/bodyfitter.py:1235-1237)
+        kid_reg = float(beta_regularizer if kid_regularizer is None else kid_regularizer)
         if B > 0:
-            h = bm._native(device)
+            h = bm._native(device, kid=self.enable_kid)
             ws = _workspace if _workspace is not None else bm._workspace(h, B, device)
             with torch.cuda.device(device):
                 stream = torch.cuda.current_stream(device).cuda_stream
                 _lib.check(_lib.load().smplfit_fit_f32(
                     h.ptr, _ptr(tv), _ptr(tj), _ptr(vw), _ptr(jw), B, int(num_iter),
-                    float(beta_regularizer), float(beta_regularizer2), int(bool(final_adjust_rots)),
-                    _ptr(pose), _ptr(betas), _ptr(trans), _ptr(orient), _ptr(rel), _ptr(ws),
-                    ws.numel(), C.c_void_p(stream)))
+                    float(beta_regularizer), float(beta_regularizer2), kid_reg,
+                    int(bool(final_adjust_rots)), _ptr(pose), _ptr(betas), _ptr(trans), _ptr(kid),
+                    _ptr(orient), _ptr(rel), _ptr(ws), ws.numel(), C.c_void_p(stream)))
         # relative_orientations = parent^T @ global of the FINAL rotations (pt/bodyfitter.py:523-533);
         # returned always (the reference returns the pre-refinement ones when neither
         # 'relative_orientations' nor 'pose_rotvecs' is requested)
         result = dict(shape_betas=betas, trans=trans, orientations=orient, relative_orientations=rel)
+        if self.enable_kid:
+            result['kid_factor'] = kid
         if 'pose_rotvecs' in requested_keys:
             result['pose_rotvecs'] = pose
         return result
 
-    def fit_with_known_pose(self, *args, **kwargs):
-        raise NotImplementedError('fit_with_known_pose is not implemented yet (pt/bodyfitter.py:552-653)')
+    def fit_with_known_pose(
+        self,
+        pose_rotvecs: torch.Tensor,
+        target_vertices: torch.Tensor,
+        target_joints: Optional[torch.Tensor] = None,
+        vertex_weights: Optional[torch.Tensor] = None,
+        joint_weights: Optional[torch.Tensor] = None,
+        beta_regularizer: float = 1,
+        beta_regularizer2: float = 0,
+        scale_regularizer: float = 0,
+        kid_regularizer: Optional[float] = None,
+        share_beta: bool = False,
+        scale_target: bool = False,
+        scale_fit: bool = False,
+        beta_regularizer_reference: Optional[torch.Tensor] = None,
+        kid_regularizer_reference: Optional[torch.Tensor] = None,
+        requested_keys: Optional[list[str]] = None,
+    ) -> dict[str, torch.Tensor]:
+        """Shape and translation for a known pose (reference pt/bodyfitter.py:552-653): global
+        rotations by forward kinematics of ``pose_rotvecs`` (the HIP forward kernel), then one shape
+        solve with the target mean added back."""
+        self._check_options(share_beta, scale_target, scale_fit, None, beta_regularizer_reference,
+                            kid_regularizer_reference)
+        bm = self.body_model
+        B = target_vertices.shape[0]
+        pose = pose_rotvecs.reshape(B, bm.num_joints * 3)
+        G = bm(pose_rotvecs=pose, return_vertices=False)['orientations']
+        kid_reg = float(beta_regularizer if kid_regularizer is None else kid_regularizer)
+        r = self._shape_solve(G, target_vertices, target_joints, vertex_weights, joint_weights,
+                              beta_regularizer, beta_regularizer2, kid_regularizer=kid_reg,
+                              add_mean=True, want_mesh=False)
+        parents = bm.kintree_parents_tensor[1:].to(G.device)
+        parent_glob = torch.cat(
+            [torch.eye(3, device=G.device).expand(B, 1, 3, 3), G.index_select(1, parents)], dim=1)
+        out = dict(shape_betas=r['shape_betas'], trans=r['trans'], orientations=G,
+                   relative_orientations=parent_glob.transpose(-1, -2) @ G)
+        if self.enable_kid:
+            out['kid_factor'] = r['kid_factor']
+        return out
 
     def fit_with_known_shape(self, *args, **kwargs):
         raise NotImplementedError('fit_with_known_shape is not implemented yet (pt/bodyfitter.py:656-838)')
@@ -134,7 +174,7 @@ class BodyFitter(nn.Module):
         tv, tj, vw, jw = prep(target_vertices), prep(target_joints), prep(vertex_weights), prep(joint_weights)
         B = tv.shape[0]
         G = torch.empty((B, bm.num_joints, 3, 3), dtype=torch.float32, device=device)
-        h = bm._native(device)
+        h = bm._native(device, kid=self.enable_kid)
         ws = bm._workspace(h, B, device)
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
@@ -144,9 +184,10 @@ class BodyFitter(nn.Module):
         return G
 
     def _shape_solve(self, glob_rotmats, target_vertices, target_joints=None, vertex_weights=None,
-                     joint_weights=None, beta_regularizer=1.0, beta_regularizer2=0.0):
-        """One shape solve for given global rotations; targets are centred internally and the
-        returned trans / vertices / joints live in the centred frame."""
+                     joint_weights=None, beta_regularizer=1.0, beta_regularizer2=0.0,
+                     kid_regularizer=None, add_mean=False, want_mesh=True):
+        """One shape solve for given global rotations; targets are centred internally and, unless
+        ``add_mean``, the returned trans / vertices / joints live in the centred frame."""
         bm = self.body_model
         device = bm.v_template.device
         prep = lambda t: None if t is None else t.to(device=device, dtype=torch.float32).contiguous()  # noqa: E731
@@ -155,14 +196,21 @@ class BodyFitter(nn.Module):
         B, J, V, S = tv.shape[0], bm.num_joints, bm.num_vertices, self.n_betas
         betas = torch.empty((B, S), dtype=torch.float32, device=device)
         trans = torch.empty((B, 3), dtype=torch.float32, device=device)
-        verts = torch.empty((B, V, 3), dtype=torch.float32, device=device)
-        joints = torch.empty((B, J, 3), dtype=torch.float32, device=device)
-        h = bm._native(device)
+        verts = torch.empty((B, V, 3), dtype=torch.float32, device=device) if want_mesh else None
+        joints = torch.empty((B, J, 3), dtype=torch.float32, device=device) if want_mesh else None
+        kid = torch.empty((B,), dtype=torch.float32, device=device) if self.enable_kid else None
+        kid_reg = float(beta_regularizer if kid_regularizer is None else kid_regularizer)
+        h = bm._native(device, kid=self.enable_kid)
         ws = bm._workspace(h, B, device)
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
             _lib.check(_lib.load().smplfit_shape_solve_f32(
                 h.ptr, _ptr(G), _ptr(tv), _ptr(tj), _ptr(vw), _ptr(jw), B, float(beta_regularizer),
-                float(beta_regularizer2), _ptr(betas), _ptr(trans), _ptr(verts), _ptr(joints),
-                _ptr(ws), ws.numel(), C.c_void_p(stream)))
-        return dict(shape_betas=betas, trans=trans, vertices=verts, joints=joints)
+                float(beta_regularizer2), kid_reg, int(bool(add_mean)), _ptr(betas), _ptr(trans),
+                _ptr(kid), _ptr(verts), _ptr(joints), _ptr(ws), ws.numel(), C.c_void_p(stream)))
+        out = dict(shape_betas=betas, trans=trans)
+        if want_mesh:
+            out.update(vertices=verts, joints=joints)
+        if self.enable_kid:
+            out['kid_factor'] = kid
+        return out

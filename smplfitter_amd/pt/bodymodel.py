@@ -70,15 +70,16 @@ class BodyModel(nn.Module):
             self.to(device)
 
     # -- native handle ---------------------------------------------------------------------------
-    def _native(self, device: torch.device) -> _lib.Handle:
-        """The C-ABI handle holding this model's constants on ``device`` (created on first use)."""
+    def _native(self, device: torch.device, kid: bool = False) -> _lib.Handle:
+        """The C-ABI handle holding this model's constants on ``device`` (created on first use).
+        ``kid=True``: the variant whose last shape unknown is the kid blend shape."""
         if device.type != 'cuda':
             raise RuntimeError(
                 'smplfitter_amd runs on MI355X through its HIP kernels only: move the model and the '
                 "inputs to a 'cuda' (ROCm) device. There is no CPU path."
             )
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        h = self._handles.get(idx)
+        h = self._handles.get((idx, kid))
         if h is None:
             reg = self.J_regressor_post_lbs
             desc, keep = _lib.make_desc(
@@ -87,10 +88,12 @@ class BodyModel(nn.Module):
                 self.J_template.cpu().numpy(), self.J_shapedirs.cpu().numpy(), self.kintree_parents,
                 reg.cpu().numpy() if reg.shape[1] == self.num_vertices else None,
                 is_smpl_family=self.model_name.startswith('smpl'),
+                kid_shapedir=self.kid_shapedir.cpu().numpy() if kid else None,
+                kid_J_shapedir=self.kid_J_shapedir.cpu().numpy() if kid else None,
             )
             with torch.cuda.device(idx):
                 h = _lib.Handle(desc)
-            self._handles[idx] = h
+            self._handles[(idx, kid)] = h
         return h
 
     @staticmethod
@@ -132,8 +135,6 @@ class BodyModel(nn.Module):
                         f'{min_ndim} dimensions, but got shape {tuple(arg.shape)}. '
                         f'For single (unbatched) inputs, use model.single() instead.'
                     )
-        if kid_factor is not None:
-            raise NotImplementedError('kid_factor is not implemented by the HIP forward kernel yet')
         device = self.v_template.device
         J, V = self.num_joints, self.num_vertices
         batch = 0
@@ -170,7 +171,11 @@ class BodyModel(nn.Module):
         tr = prep(trans)
         if tr is not None and tr.shape[0] != batch:
             tr = tr.expand(batch, 3).contiguous()
-        h = self._native(device)
+        kid = None
+        if kid_factor is not None:
+            kid = torch.as_tensor(kid_factor, dtype=torch.float32, device=device).reshape(-1)
+            kid = kid.expand(batch).contiguous() if kid.numel() == 1 else kid.contiguous()
+        h = self._native(device, kid=kid is not None)
         ws = self._workspace(h, batch, device)
         joints = torch.empty((batch, J, 3), dtype=torch.float32, device=device)
         orient = torch.empty((batch, J, 3, 3), dtype=torch.float32, device=device)
@@ -178,7 +183,7 @@ class BodyModel(nn.Module):
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
             _lib.check(_lib.load().smplfit_forward_f32(
-                h.ptr, _ptr(pose), _ptr(glob), _ptr(betas), nb, _ptr(tr), batch, _ptr(verts),
+                h.ptr, _ptr(pose), _ptr(glob), _ptr(betas), nb, _ptr(tr), _ptr(kid), batch, _ptr(verts),
                 _ptr(joints), _ptr(orient), _ptr(ws), ws.numel(), C.c_void_p(stream)))
         res = dict(joints=joints, orientations=orient)
         if return_vertices:

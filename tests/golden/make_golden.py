@@ -110,6 +110,38 @@ def make_kind(kind, root, subset=None):
         out['stage.trans0'] = sh['trans'].numpy()
         out['stage.vertices0_sub'] = sh['vertices'].numpy()[:, ::300]
         out['stage.joints0'] = sh['joints'].numpy()
+        if subset is None:
+            # kid blend shape (enable_kid): forward with kid_factor, fits with the extra unknown, the
+            # known-pose solve, and BodyConverter's default call (same-topology models -> no CSR):
+            # fit(enable_kid, beta_regularizer=0, final_adjust_rots=False, kid_regularizer=1e9)
+            kid = (rs.randn(B) * 0.3).astype(np.float32)
+            out['kid'] = kid
+            fwk = model(torch.from_numpy(pose), torch.from_numpy(betas), torch.from_numpy(trans),
+                        kid_factor=torch.from_numpy(kid))
+            out['kid.fwd_vertices_sub'] = fwk['vertices'].numpy()[:, ::300]
+            out['kid.fwd_joints'] = fwk['joints'].numpy()
+            out['kid.target_vertices'] = fwk['vertices'].numpy()
+            out['kid.target_joints'] = fwk['joints'].numpy()
+            kfitter = ref.BodyFitter(model, enable_kid=True)
+            for tag, kw in (
+                ('a', dict(num_iter=3, beta_regularizer=1.0, use_joints=True)),
+                ('b', dict(num_iter=1, beta_regularizer=0.0, final_adjust_rots=False, kid_regularizer=1e9, use_joints=False)),
+                ('c', dict(num_iter=3, beta_regularizer=0.0, kid_regularizer=0.0, use_joints=True)),
+            ):
+                kw = dict(kw)
+                uj = kw.pop('use_joints')
+                r = kfitter.fit(fwk['vertices'], fwk['joints'] if uj else None,
+                                requested_keys=['pose_rotvecs', 'shape_betas', 'trans'], **kw)
+                for k in ('pose_rotvecs', 'shape_betas', 'trans', 'kid_factor', 'orientations'):
+                    out[f'kidfit.{tag}.{k}'] = r[k].numpy()
+            r = fitter.fit_with_known_pose(torch.from_numpy(pose), tv, tj, beta_regularizer=1.0)
+            out['knownpose.shape_betas'] = r['shape_betas'].numpy()
+            out['knownpose.trans'] = r['trans'].numpy()
+            conv = ref.BodyConverter(model, model)
+            for ni in (1, 3):
+                r = conv.convert(torch.from_numpy(pose), torch.from_numpy(betas), torch.from_numpy(trans), num_iter=ni)
+                for k in ('pose_rotvecs', 'shape_betas', 'trans'):
+                    out[f'convert.it{ni}.{k}'] = r[k].numpy()
     path = osp.join(HERE, f'golden_{name}.npz')
     np.savez_compressed(path, **out)
     print(path, f'{os.path.getsize(path) / 1e6:.2f} MB', len(out), 'arrays')

@@ -26,6 +26,7 @@ sf::JointTabs make_tabs(const sf::HostTables& t) {
   sf::JointTabs jt;
   jt.J = t.J; jt.S = t.S; jt.num_levels = t.num_levels(); jt.adj_last_level = t.adj_last_level;
   jt.P = t.P; jt.Kp = t.Kp;
+  jt.n_kid = t.n_kid;
   jt.parents = t.parents.data(); jt.fk_js = t.fk_js.data();
   jt.fk_level_start = t.fk_level_start.data(); jt.cas_start = t.cas_start.data();
   jt.cas_flat = t.cas_flat.data(); jt.part_type = t.part_type.data(); jt.toe_src = t.toe_src.data();
@@ -223,13 +224,13 @@ struct Emu {
     }
   }
 
-  void k4(float reg, float reg2) {
+  void k4(float reg, float reg2, float kid_reg) {
     const int J = t.J, NE1 = sf::ne_size(S) + 1;
     HostCtx cx;
     for (int b = 0; b < B; ++b)
       sf::solve_stage(cx, jt, solve_base(), gramv.data() + (size_t)b * NE1, gramj.data() + (size_t)b * NE1,
                       pext.data() + (size_t)b * J * 3 * (S + 1), jd_b(b),
-                      use_pair_gram ? mbj.data() + (size_t)b * J * 3 : nullptr, reg, reg2,
+                      use_pair_gram ? mbj.data() + (size_t)b * J * 3 : nullptr, reg, reg2, kid_reg,
                       beta.data() + (size_t)b * S, trans.data() + (size_t)b * 3,
                       rjoints.data() + (size_t)b * J * 3, jb.data() + (size_t)b * J * 4);
   }
@@ -269,8 +270,8 @@ thread_local std::string g_err;
 
 template <int S, int KW>
 int fit_impl(const sf::HostTables& t, const float* tv, const float* tj, const float* vw,
-             const float* jw, int B, int num_iter, float reg, float reg2, int final_adjust,
-             float* pose, float* betas, float* trans, float* orient, float* G0_out) {
+             const float* jw, int B, int num_iter, float reg, float reg2, float kid_reg, int final_adjust,
+             float* pose, float* betas, float* trans, float* kid, float* orient, float* G0_out) {
   Emu<S, KW> e(t, B);
   const bool joints = tj != nullptr;
   const bool eff_v = joints ? (vw && jw) : (vw != nullptr);
@@ -292,7 +293,7 @@ int fit_impl(const sf::HostTables& t, const float* tv, const float* tj, const fl
   for (int it = 0; it < num_iter; ++it) {
     e.gemm();
     e.k3(eff_v);
-    e.k4(reg, reg2);
+    e.k4(reg, reg2, kid_reg);
     const bool last = it + 1 == num_iter;
     if (last && !final_adjust) break;
     e.k5(vw != nullptr, !joints);
@@ -310,14 +311,15 @@ int fit_impl(const sf::HostTables& t, const float* tv, const float* tj, const fl
                      e.rjoints.data() + (size_t)b * t.J * 3, jw ? jw + (size_t)b * t.J : nullptr,
                      e.G.data() + (size_t)b * t.J * 9, e.beta.data() + (size_t)b * S,
                      e.trans.data() + (size_t)b * 3, e.mean.data() + (size_t)b * 3, final_adjust != 0,
-                     pose + (size_t)b * t.J * 3, betas + (size_t)b * S, trans + (size_t)b * 3,
-                     orient ? orient + (size_t)b * t.J * 9 : nullptr, nullptr);
+                     pose + (size_t)b * t.J * 3, betas + (size_t)b * (S - t.n_kid), trans + (size_t)b * 3,
+                     kid ? kid + b : nullptr, orient ? orient + (size_t)b * t.J * 9 : nullptr, nullptr);
   return 0;
 }
 
 template <int S, int KW>
 int forward_impl(const sf::HostTables& t, const float* pose, const float* glob, const float* betas,
-                 int nb, const float* trans, int B, float* verts, float* joints, float* orient) {
+                 int nb, const float* trans, const float* kid, int B, float* verts, float* joints,
+                 float* orient) {
   Emu<S, KW> e(t, B);
   HostCtx cx;
   const float zero3[3] = {0, 0, 0};
@@ -325,7 +327,7 @@ int forward_impl(const sf::HostTables& t, const float* pose, const float* glob, 
     sf::forward_joint_stage(cx, e.jt, e.sh, pose ? pose + (size_t)b * t.J * 3 : nullptr,
                             glob ? glob + (size_t)b * t.J * 9 : nullptr,
                             betas ? betas + (size_t)b * nb : nullptr, betas ? nb : 0,
-                            trans ? trans + (size_t)b * 3 : nullptr, e.rp.data() + (size_t)b * t.Kp,
+                            kid ? kid + b : nullptr, trans ? trans + (size_t)b * 3 : nullptr, e.rp.data() + (size_t)b * t.Kp,
                             e.jd_b(b), joints + (size_t)b * t.J * 3,
                             orient ? orient + (size_t)b * t.J * 9 : nullptr);
     for (int k = 0; k < t.J * 3; ++k)
@@ -336,7 +338,10 @@ int forward_impl(const sf::HostTables& t, const float* pose, const float* glob, 
     for (int b = 0; b < B; ++b)
       for (int i = 0; i < t.V; ++i) {
         float v[3];
-        e.vertex(b, i, betas ? betas + (size_t)b * nb : nullptr, nb, trans ? trans + (size_t)b * 3 : zero3, v);
+        float bb[S];
+        for (int q = 0; q < S; ++q) bb[q] = (betas && q < nb) ? betas[(size_t)b * nb + q] : 0.f;
+        if (kid && t.n_kid) bb[S - 1] = kid[b];
+        e.vertex(b, i, bb, S, trans ? trans + (size_t)b * 3 : zero3, v);
         for (int c = 0; c < 3; ++c) verts[((size_t)b * t.V + t.perm[i]) * 3 + c] = v[c];
       }
   }
@@ -356,32 +361,36 @@ void hostemu_rotvec2mat(const float* rv, float* R, int n) { for (int i = 0; i < 
 void hostemu_align(const float* a, const float* b, float* R, int n) { for (int i = 0; i < n; ++i) sf::align_unit_vectors(a + i * 3, b + i * 3, R + i * 9); }
 
 int hostemu_fit(const smplfit_model_desc* d, const float* tv, const float* tj, const float* vw,
-                const float* jw, int B, int num_iter, float reg, float reg2, int final_adjust,
-                float* pose, float* betas, float* trans, float* orient, float* G0_out) {
+                const float* jw, int B, int num_iter, float reg, float reg2, float kid_reg,
+                int final_adjust, float* pose, float* betas, float* trans, float* kid, float* orient,
+                float* G0_out) {
   sf::HostTables t;
   bool unsup = false;
   g_err = sf::build_tables(*d, t, &unsup);
   if (!g_err.empty()) return -1;
   if (t.S == 10 && t.KW == 4)
-    return fit_impl<10, 4>(t, tv, tj, vw, jw, B, num_iter, reg, reg2, final_adjust, pose, betas, trans, orient, G0_out);
+    return fit_impl<10, 4>(t, tv, tj, vw, jw, B, num_iter, reg, reg2, kid_reg, final_adjust, pose, betas, trans, kid, orient, G0_out);
   if (t.S == 10 && t.KW == 8)
-    return fit_impl<10, 8>(t, tv, tj, vw, jw, B, num_iter, reg, reg2, final_adjust, pose, betas, trans, orient, G0_out);
+    return fit_impl<10, 8>(t, tv, tj, vw, jw, B, num_iter, reg, reg2, kid_reg, final_adjust, pose, betas, trans, kid, orient, G0_out);
   if (t.S == 16 && t.KW == 4)
-    return fit_impl<16, 4>(t, tv, tj, vw, jw, B, num_iter, reg, reg2, final_adjust, pose, betas, trans, orient, G0_out);
+    return fit_impl<16, 4>(t, tv, tj, vw, jw, B, num_iter, reg, reg2, kid_reg, final_adjust, pose, betas, trans, kid, orient, G0_out);
+  if (t.S == 11 && t.KW == 4)
+    return fit_impl<11, 4>(t, tv, tj, vw, jw, B, num_iter, reg, reg2, kid_reg, final_adjust, pose, betas, trans, kid, orient, G0_out);
   g_err = "hostemu: unsupported (S, KW)";
   return -2;
 }
 
 int hostemu_forward(const smplfit_model_desc* d, const float* pose, const float* glob,
-                    const float* betas, int nb, const float* trans, int B, float* verts,
-                    float* joints, float* orient) {
+                    const float* betas, int nb, const float* trans, const float* kid, int B,
+                    float* verts, float* joints, float* orient) {
   sf::HostTables t;
   bool unsup = false;
   g_err = sf::build_tables(*d, t, &unsup);
   if (!g_err.empty()) return -1;
-  if (t.S == 10 && t.KW == 4) return forward_impl<10, 4>(t, pose, glob, betas, nb, trans, B, verts, joints, orient);
-  if (t.S == 10 && t.KW == 8) return forward_impl<10, 8>(t, pose, glob, betas, nb, trans, B, verts, joints, orient);
-  if (t.S == 16 && t.KW == 4) return forward_impl<16, 4>(t, pose, glob, betas, nb, trans, B, verts, joints, orient);
+  if (t.S == 10 && t.KW == 4) return forward_impl<10, 4>(t, pose, glob, betas, nb, trans, kid, B, verts, joints, orient);
+  if (t.S == 10 && t.KW == 8) return forward_impl<10, 8>(t, pose, glob, betas, nb, trans, kid, B, verts, joints, orient);
+  if (t.S == 16 && t.KW == 4) return forward_impl<16, 4>(t, pose, glob, betas, nb, trans, kid, B, verts, joints, orient);
+  if (t.S == 11 && t.KW == 4) return forward_impl<11, 4>(t, pose, glob, betas, nb, trans, kid, B, verts, joints, orient);
   g_err = "hostemu: unsupported (S, KW)";
   return -2;
 }

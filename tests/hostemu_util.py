@@ -34,9 +34,9 @@ def load():
         os.replace(tmp, SO)
     lib = C.CDLL(SO)
     vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
-    lib.hostemu_fit.argtypes = [C.POINTER(_lib.ModelDesc), vp, vp, vp, vp, i32, i32, f32, f32, i32, vp, vp, vp, vp, vp]
+    lib.hostemu_fit.argtypes = [C.POINTER(_lib.ModelDesc), vp, vp, vp, vp, i32, i32, f32, f32, f32, i32, vp, vp, vp, vp, vp, vp]
     lib.hostemu_fit.restype = i32
-    lib.hostemu_forward.argtypes = [C.POINTER(_lib.ModelDesc), vp, vp, vp, i32, vp, i32, vp, vp, vp]
+    lib.hostemu_forward.argtypes = [C.POINTER(_lib.ModelDesc), vp, vp, vp, i32, vp, vp, i32, vp, vp, vp]
     lib.hostemu_forward.restype = i32
     lib.hostemu_last_error.restype = C.c_char_p
     for fn in ('hostemu_proj_so3', 'hostemu_mat2rotvec', 'hostemu_rotvec2mat'):
@@ -50,19 +50,23 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def desc_from_md(md, kind='smpl'):
+def desc_from_md(md, kind='smpl', enable_kid=False):
     return _lib.make_desc(
         md.v_template, md.shapedirs, md.posedirs, md.weights, md.J_template, md.J_shapedirs,
         md.kintree_parents,
         md.J_regressor_post_lbs if md.J_regressor_post_lbs.shape[1] == md.num_vertices else None,
         is_smpl_family=kind.startswith('smpl'),
+        kid_shapedir=md.kid_shapedir if enable_kid else None,
+        kid_J_shapedir=md.kid_J_shapedir if enable_kid else None,
     )
 
 
 def fit(md, kind, tv, tj=None, vw=None, jw=None, num_iter=1, beta_regularizer=1.0,
-        beta_regularizer2=0.0, final_adjust_rots=True):
+        beta_regularizer2=0.0, final_adjust_rots=True, enable_kid=False, kid_regularizer=None):
     lib = load()
-    desc, keep = desc_from_md(md, kind)
+    desc, keep = desc_from_md(md, kind, enable_kid)
+    if kid_regularizer is None:
+        kid_regularizer = beta_regularizer
     f = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)  # noqa: E731
     tv, tj, vw, jw = f(tv), f(tj), f(vw), f(jw)
     B, J, S = tv.shape[0], md.num_joints, md.shapedirs.shape[2]
@@ -71,26 +75,30 @@ def fit(md, kind, tv, tj=None, vw=None, jw=None, num_iter=1, beta_regularizer=1.
     trans = np.zeros((B, 3), np.float32)
     orient = np.zeros((B, J, 3, 3), np.float32)
     G0 = np.zeros((B, J, 3, 3), np.float32)
+    kid = np.zeros((B,), np.float32)
     rc = lib.hostemu_fit(C.byref(desc), _p(tv), _p(tj), _p(vw), _p(jw), B, num_iter, beta_regularizer,
-                         beta_regularizer2, int(final_adjust_rots), _p(pose), _p(betas), _p(trans),
-                         _p(orient), _p(G0))
+                         beta_regularizer2, kid_regularizer, int(final_adjust_rots), _p(pose), _p(betas),
+                         _p(trans), _p(kid), _p(orient), _p(G0))
     if rc != 0:
         raise RuntimeError(lib.hostemu_last_error().decode())
-    return dict(pose_rotvecs=pose, shape_betas=betas, trans=trans, orientations=orient, glob_rotmats_iter0=G0)
+    out = dict(pose_rotvecs=pose, shape_betas=betas, trans=trans, orientations=orient, glob_rotmats_iter0=G0)
+    if enable_kid:
+        out['kid_factor'] = kid
+    return out
 
 
-def forward(md, kind, pose=None, betas=None, trans=None, glob=None):
+def forward(md, kind, pose=None, betas=None, trans=None, glob=None, kid=None):
     lib = load()
-    desc, keep = desc_from_md(md, kind)
+    desc, keep = desc_from_md(md, kind, kid is not None)
     f = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)  # noqa: E731
-    pose, betas, trans, glob = f(pose), f(betas), f(trans), f(glob)
+    pose, betas, trans, glob, kid = f(pose), f(betas), f(trans), f(glob), f(kid)
     B = (pose if pose is not None else glob).shape[0]
     J, V = md.num_joints, md.num_vertices
     verts = np.zeros((B, V, 3), np.float32)
     joints = np.zeros((B, J, 3), np.float32)
     orient = np.zeros((B, J, 3, 3), np.float32)
     rc = lib.hostemu_forward(C.byref(desc), _p(pose), _p(glob), _p(betas), 0 if betas is None else betas.shape[1],
-                             _p(trans), B, _p(verts), _p(joints), _p(orient))
+                             _p(trans), _p(kid), B, _p(verts), _p(joints), _p(orient))
     if rc != 0:
         raise RuntimeError(lib.hostemu_last_error().decode())
     return dict(vertices=verts, joints=joints, orientations=orient)

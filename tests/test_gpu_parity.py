@@ -229,3 +229,77 @@ print("PAIR_FORM_OK")
     r = subprocess.run([sys.executable, '-c', code, model_root], cwd=root_dir, env=env,
                        capture_output=True, text=True, timeout=300)
     assert 'PAIR_FORM_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize('name', ['smpl', 'smplx'])
+def test_kid_knownpose_converter(name, model_root, golden, dev):
+    """enable_kid fits, forward with kid_factor, fit_with_known_pose and
+    BodyConverter.convert (same topology) against the reference's outputs."""
+    from smplfitter_amd.pt import BodyConverter, BodyFitter
+
+    g = golden(name)
+    kind, md = util.load_md(model_root, name, g)
+    om, _ = util.make_oracle(md, kind, np.float64)
+    m, f = get_model(model_root, name, g, dev)
+    fw = to_np(m(t(g['pose'], dev), t(g['betas'], dev), t(g['trans'], dev), kid_factor=t(g['kid'], dev)))
+    assert np.abs(fw['vertices'] - g['kid.target_vertices']).max() < 2e-6
+    assert np.abs(fw['joints'] - g['kid.fwd_joints']).max() < 2e-6
+    kf = BodyFitter(m, enable_kid=True)
+    cfgs = dict(
+        a=dict(num_iter=3, beta_regularizer=1.0, use_joints=True),
+        b=dict(num_iter=1, beta_regularizer=0.0, final_adjust_rots=False, kid_regularizer=1e9, use_joints=False),
+        c=dict(num_iter=3, beta_regularizer=0.0, kid_regularizer=0.0, use_joints=True),
+    )
+    for tag, kw in cfgs.items():
+        kw = dict(kw)
+        uj = kw.pop('use_joints')
+        o = to_np(kf.fit(t(g['kid.target_vertices'], dev), t(g['kid.target_joints'], dev) if uj else None, **kw))
+        ref = {k: g[f'kidfit.{tag}.{k}'] for k in ('pose_rotvecs', 'shape_betas', 'trans', 'kid_factor')}
+        va = om.forward(o['pose_rotvecs'], o['shape_betas'], o['trans'], kid_factor=o['kid_factor'])['vertices']
+        vb = om.forward(ref['pose_rotvecs'], ref['shape_betas'], ref['trans'], kid_factor=ref['kid_factor'])['vertices']
+        assert np.linalg.norm(va - vb, axis=-1).max() < 1e-4, tag
+        assert np.abs(o['trans'] - ref['trans']).max() < 2e-5, tag
+        if tag != 'c':
+            assert np.abs(o['shape_betas'] - ref['shape_betas']).max() < 1e-3, tag
+            assert np.abs(o['kid_factor'] - ref['kid_factor']).max() < 1e-3, tag
+    r = to_np(f.fit_with_known_pose(t(g['pose'], dev), t(g['target_vertices'], dev), t(g['target_joints'], dev),
+                                    beta_regularizer=1.0))
+    assert np.abs(r['shape_betas'] - g['knownpose.shape_betas']).max() < 1e-4
+    assert np.abs(r['trans'] - g['knownpose.trans']).max() < 1e-5
+    conv = BodyConverter(m, m)
+    for ni in (1, 3):
+        o = to_np(conv.convert(t(g['pose'], dev), t(g['betas'], dev), t(g['trans'], dev), num_iter=ni))
+        ref = {k: g[f'convert.it{ni}.{k}'] for k in ('pose_rotvecs', 'shape_betas', 'trans')}
+        assert set(o) == {'pose_rotvecs', 'shape_betas', 'trans'}
+        assert util.vertex_l2(om, o, ref) < 1e-4, ni
+        assert np.abs(o['trans'] - ref['trans']).max() < 2e-5, ni
+
+
+def test_convert_vertices_sparse(model_root, golden, dev, tmp_path, monkeypatch):
+    """Topology transfer of BodyConverter.convert_vertices: (V_out x V_in) CSR applied to a batch
+    (reference pt/bodyconverter.py:128-149), with a synthetic barycentric matrix in the official
+    file layout (columns duplicated, first half used; reference common.py:425-429)."""
+    import pickle
+
+    import scipy.sparse as sp
+
+    from smplfitter_amd.pt import BodyConverter
+
+    g, gx = golden('smpl'), golden('smplx')
+    m, _ = get_model(model_root, 'smpl', g, dev)
+    mx, _ = get_model(model_root, 'smplx', gx, dev)
+    rs = np.random.RandomState(3)
+    rows = np.repeat(np.arange(10475), 3)
+    cols = rs.randint(0, 6890, size=rows.shape)
+    w = rs.dirichlet([1, 1, 1], size=10475).reshape(-1).astype(np.float32)
+    mat = sp.csr_matrix((w, (rows, cols)), shape=(10475, 6890))
+    os_dir = tmp_path / 'body_models'
+    os_dir.mkdir()
+    with open(os_dir / 'smpl2smplx_deftrafo_setup.pkl', 'wb') as fh:
+        pickle.dump(dict(mtx=sp.hstack([mat, mat]).tocsr()), fh)
+    monkeypatch.setenv('DATA_ROOT', str(tmp_path))
+    conv = BodyConverter(m, mx)
+    v = t(g['target_vertices'], dev)
+    out = conv.convert_vertices(v).cpu().numpy()
+    ref = np.einsum('ov,bvc->boc', mat.toarray(), g['target_vertices'])
+    assert out.shape == (4, 10475, 3) and np.abs(out - ref).max() < 1e-5

@@ -78,3 +78,29 @@ def test_fit_goldens(name, model_root, golden):
         if cfg['joints'] and not cfg['weights']:
             G0 = o['glob_rotmats_iter0']
     assert np.abs(G0 - g['stage.glob_rotmats_iter0']).max() < (2e-3 if name == 'smplx' else 5e-4)
+
+
+@pytest.mark.parametrize('name', ['smpl'])
+def test_kid_goldens(name, model_root, golden):
+    g = golden(name)
+    kind, md = util.load_md(model_root, name, g)
+    om, _ = util.make_oracle(md, kind, np.float64)
+    fw = H.forward(md, kind, g['pose'], g['betas'], g['trans'], kid=g['kid'])
+    assert np.abs(fw['vertices'] - g['kid.target_vertices']).max() < 2e-6
+    assert np.abs(fw['joints'] - g['kid.fwd_joints']).max() < 2e-6
+    cfgs = dict(
+        a=dict(num_iter=3, beta_regularizer=1.0, use_joints=True),
+        b=dict(num_iter=1, beta_regularizer=0.0, final_adjust_rots=False, kid_regularizer=1e9, use_joints=False),
+    )
+    for tag, kw in cfgs.items():
+        kw = dict(kw)
+        uj = kw.pop('use_joints')
+        o = H.fit(md, kind, g['kid.target_vertices'], g['kid.target_joints'] if uj else None,
+                  enable_kid=True, **kw)
+        ref = {k: g[f'kidfit.{tag}.{k}'] for k in ('pose_rotvecs', 'shape_betas', 'trans', 'kid_factor')}
+        va = om.forward(o['pose_rotvecs'], o['shape_betas'], o['trans'], kid_factor=o['kid_factor'])['vertices']
+        vb = om.forward(ref['pose_rotvecs'], ref['shape_betas'], ref['trans'], kid_factor=ref['kid_factor'])['vertices']
+        assert np.linalg.norm(va - vb, axis=-1).max() < 1e-4, tag
+        assert np.abs(o['shape_betas'] - ref['shape_betas']).max() < 1e-3, tag
+        assert np.abs(o['kid_factor'] - ref['kid_factor']).max() < 1e-3, tag
+        assert np.abs(o['trans'] - ref['trans']).max() < 2e-5, tag

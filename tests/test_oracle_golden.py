@@ -95,3 +95,43 @@ def test_primitive_goldens(golden):
     # last 4 pairs are antiparallel: the reference's answer there is a 180-degree turn about a
     # rounding-noise axis ("arbitrary", pt/rotation.py:217) — only the defined cases are pinned
     assert np.abs(Ra[:-4] - g['align_out'][:-4]).max() < 1e-6
+
+
+@pytest.mark.parametrize('name', ['smpl', 'smplx'])
+def test_kid_knownpose_converter_goldens(name, model_root, golden):
+    """enable_kid fits (the extra blend-shape unknown), forward with kid_factor, fit_with_known_pose
+    and BodyConverter's default call (same topology: fit(enable_kid, beta_reg=0, kid_reg=1e9,
+    final_adjust_rots=False, joints omitted)) against the reference's outputs."""
+    g = golden(name)
+    kind, md = util.load_md(model_root, name, g)
+    om, of = util.make_oracle(md, kind, np.float64)
+    fw = om.forward(g['pose'], g['betas'], g['trans'], kid_factor=g['kid'])
+    assert np.abs(fw['vertices'] - g['kid.target_vertices']).max() < 2e-6
+    assert np.abs(fw['joints'] - g['kid.fwd_joints']).max() < 2e-6
+    kf = O.OracleFitter(om, enable_kid=True)
+    cfgs = dict(
+        a=dict(num_iter=3, beta_regularizer=1.0, use_joints=True),
+        b=dict(num_iter=1, beta_regularizer=0.0, final_adjust_rots=False, kid_regularizer=1e9, use_joints=False),
+        c=dict(num_iter=3, beta_regularizer=0.0, kid_regularizer=0.0, use_joints=True),
+    )
+    for tag, kw in cfgs.items():
+        kw = dict(kw)
+        uj = kw.pop('use_joints')
+        o = kf.fit(g['kid.target_vertices'], g['kid.target_joints'] if uj else None, **kw)
+        ref = {k: g[f'kidfit.{tag}.{k}'] for k in ('pose_rotvecs', 'shape_betas', 'trans', 'kid_factor')}
+        va = om.forward(o['pose_rotvecs'], o['shape_betas'], o['trans'], kid_factor=o['kid_factor'])['vertices']
+        vb = om.forward(ref['pose_rotvecs'], ref['shape_betas'], ref['trans'], kid_factor=ref['kid_factor'])['vertices']
+        assert np.linalg.norm(va - vb, axis=-1).max() < 1e-4, tag
+        assert np.abs(o['trans'] - ref['trans']).max() < 2e-5, tag
+        if tag != 'c':  # c: betas and kid direction are nearly collinear -> only the mesh is pinned
+            assert np.abs(o['shape_betas'] - ref['shape_betas']).max() < 1e-3, tag
+            assert np.abs(o['kid_factor'] - ref['kid_factor']).max() < 1e-3, tag
+    r = of.fit_with_known_pose(g['pose'], g['target_vertices'], g['target_joints'], beta_regularizer=1.0)
+    assert np.abs(r['shape_betas'] - g['knownpose.shape_betas']).max() < 1e-4
+    assert np.abs(r['trans'] - g['knownpose.trans']).max() < 1e-5
+    for ni in (1, 3):  # BodyConverter.convert with identical in/out topology
+        o = kf.fit(g['target_vertices'], None, num_iter=ni, beta_regularizer=0.0, final_adjust_rots=False,
+                   kid_regularizer=1e9)
+        ref = {k: g[f'convert.it{ni}.{k}'] for k in ('pose_rotvecs', 'shape_betas', 'trans')}
+        assert util.vertex_l2(om, o, ref) < 1e-4, ni
+        assert np.abs(o['trans'] - ref['trans']).max() < 2e-5, ni
