@@ -1,3 +1,5 @@
+#!/bin/bash
+# PMC passes for the fit kernels (separate passes: TCC slots; no trace domains besides kernel-trace).
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
 run() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_$name -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_$name.log 2>&1; }
 run a SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
@@ -5,5 +7,4 @@ run b SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_ID
 run c TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 run d FETCH_SIZE
 run e WRITE_SIZE
-rocprofv3 -L 2>/dev/null | grep -oE "^\s*(SQ_[A-Z_0-9]+|TCP_[A-Z_0-9]+|TCC_[A-Z_0-9]+)" | sort -u | tr '\n' ' ' > $R/gpurun_out/counters.txt
-ls $R/gpurun_out/pmc_a | head
+run f SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CU_CYCLES
