@@ -389,8 +389,10 @@ class OracleFitter:
         return out
 
     # -- dependent refinement, level-batched branch (pt/bodyfitter.py:1418-1544) -------------------
-    def fit_global_rotations_dependent(self, tv, tj, rv, rj_true, vw, jw, G, beta, trans):
-        """beta: all shape unknowns (betas + kid when enabled)."""
+    def fit_global_rotations_dependent(self, tv, tj, rv, rj_true, vw, jw, G, beta, trans,
+                                       rest_joints=None, scale_corr=None):
+        """beta: all shape unknowns (betas + kid when enabled); ``rest_joints`` overrides the rest-pose
+        joints computed from it (known-shape entry point); ``scale_corr`` (B,1,1) scales them (:1449-1450)."""
         m, dt, J, par = self.m, self.m.dtype, self.m.J, self.m.parents
         B = tv.shape[0]
         if tj is None:
@@ -398,7 +400,12 @@ class OracleFitter:
             rj = np.einsum('jv,bvc->bjc', m.J_regressor_post_lbs, rv)
         else:
             rj = rj_true
-        j = self.J_ext[None, :, :, 0] + np.einsum('jcs,bs->bjc', self.J_ext[:, :, 1:], beta)
+        if rest_joints is not None:
+            j = rest_joints
+        else:
+            j = self.J_ext[None, :, :, 0] + np.einsum('jcs,bs->bjc', self.J_ext[:, :, 1:], beta)
+        if scale_corr is not None:
+            j = j * scale_corr
         jpar = np.concatenate([np.zeros((B, 1, 3), dt), j[:, par[1:]]], 1)
         bones = j - jpar
         raw, st, sa, sw = self.part_sums(tv, rv, vw)
@@ -502,3 +509,75 @@ class OracleFitter:
         if self.enable_kid:
             out['kid_factor'] = r['kid_factor']
         return out
+
+    # -- pose + translation for a known shape (pt/bodyfitter.py:655-838) -----------------------------
+    def fit_with_known_shape(self, shape_betas, target_vertices, target_joints=None,
+                             vertex_weights=None, joint_weights=None, kid_factor=None, num_iter=1,
+                             final_adjust_rots=True, initial_pose_rotvecs=None, scale_fit=False):
+        m, dt, J, par = self.m, self.m.dtype, self.m.J, self.m.parents
+        tv = np.asarray(target_vertices, dt)
+        tj = None if target_joints is None else np.asarray(target_joints, dt)
+        vw = None if vertex_weights is None else np.asarray(vertex_weights, dt)
+        jw = None if joint_weights is None else np.asarray(joint_weights, dt)
+        betas = np.asarray(shape_betas, dt)
+        B = tv.shape[0]
+        if tj is None:  # (:710-717)
+            mean = tv.mean(1)
+            tv = tv - mean[:, None]
+        else:
+            mean = np.concatenate([tv, tj], 1).mean(1)
+            tv, tj = tv - mean[:, None], tj - mean[:, None]
+        pose0 = (np.zeros((B, 3 * J), dt) if initial_pose_rotvecs is None
+                 else np.asarray(initial_pose_rotvecs, dt))
+        f = m.forward(pose_rotvecs=pose0, shape_betas=betas, kid_factor=kid_factor)  # (:719-723)
+        G = self.fit_global_rotations(tv, tj, f['vertices'], f['joints'], vw, jw) @ f['orientations']
+        for _ in range(num_iter - 1):  # (:740-757)
+            f = m.forward(glob_rotmats=G, shape_betas=betas, kid_factor=kid_factor)
+            rj = f['joints'] if tj is not None else None
+            G = self.fit_global_rotations(tv, tj, f['vertices'], rj, vw, jw) @ G
+        f = m.forward(glob_rotmats=G, shape_betas=betas, kid_factor=kid_factor)
+        rv, rj = f['vertices'], f['joints']
+        scale, trans = fit_scale_and_translation(tv, rv, tj, rj, vw, jw, scale_fit)
+        if final_adjust_rots:  # (:774-802)
+            nb = min(betas.shape[1], m.S)
+            rest = m.J_template + np.einsum('jcs,bs->bjc', m.J_shapedirs[:, :, :nb], betas[:, :nb])
+            if kid_factor is not None:
+                rest = rest + m.kid_J_shapedir[None] * np.asarray(kid_factor, dt).reshape(-1, 1, 1)
+            sc = None if scale is None else scale[:, None, None]
+            sv = rv if scale is None else sc * rv
+            sj = rj if scale is None else sc * rj
+            G = self.fit_global_rotations_dependent(
+                tv, tj, (sv + trans[:, None]).astype(dt), (sj + trans[:, None]).astype(dt), vw, jw, G,
+                None, trans, rest_joints=rest.astype(dt), scale_corr=sc)
+        Gpar = np.concatenate([np.broadcast_to(np.eye(3, dtype=dt), (B, 1, 3, 3)), G[:, par[1:]]], 1)
+        rel = np.swapaxes(Gpar, -1, -2) @ G
+        out = dict(pose_rotvecs=mat2rotvec(rel).reshape(B, J * 3), trans=(trans + mean).astype(dt),
+                   orientations=G, relative_orientations=rel)
+        if scale is not None:
+            out['scale_corr'] = scale
+        return out
+
+
+def fit_scale_and_translation(tv, rv, tj, rj, vw=None, jw=None, scale=False):
+    """Weighted similarity alignment without rotation (pt/bodyfitter.py:1628-1681): returns
+    (scale (B,) or None, trans (B,3)) with target ~ scale * reference + trans."""
+    dt = tv.dtype
+    if tj is None or rj is None:
+        t_both, r_both = tv, rv
+        w = vw if vw is not None else np.ones(tv.shape[:2], dt)
+    else:
+        t_both, r_both = np.concatenate([tv, tj], 1), np.concatenate([rv, rj], 1)
+        if vw is not None and jw is not None:
+            w = np.concatenate([vw, jw], 1)
+        else:
+            w = np.ones(t_both.shape[:2], dt)
+    w = (w / w.sum(1, keepdims=True)).astype(dt)
+    mt = (t_both * w[..., None]).sum(1)
+    mr = (r_both * w[..., None]).sum(1)
+    if not scale:
+        return None, (mt - mr).astype(dt)
+    tc, rc = t_both - mt[:, None], r_both - mr[:, None]
+    ssq_r = (rc ** 2 * w[..., None]).sum((1, 2))
+    ssq_t = (tc ** 2 * w[..., None]).sum((1, 2))
+    sf = np.sqrt(ssq_t / ssq_r).astype(dt)
+    return sf, (mt - sf[:, None] * mr).astype(dt)

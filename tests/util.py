@@ -42,3 +42,47 @@ def vertex_l2(om64, a, b):
     va = om64.forward(a['pose_rotvecs'], a['shape_betas'], a['trans'])['vertices']
     vb = om64.forward(b['pose_rotvecs'], b['shape_betas'], b['trans'])['vertices']
     return float(np.linalg.norm(va - vb, axis=-1).max())
+
+
+# ---- inputs of the extended fixtures (tests/golden/make_golden_ext.py), shared with the tests ------
+# case -> (num_iter, joints, weights, scale_fit, kid, initial_pose, final_adjust)
+KNOWN_SHAPE_CASES = {
+    'a': (1, True, False, False, False, False, True),
+    'b': (3, False, True, False, False, False, True),
+    'c': (2, True, True, True, False, False, True),
+    'd': (2, True, False, False, True, True, False),
+    'e': (3, True, False, True, False, True, True),
+    'f': (1, False, False, False, False, False, True),
+}
+
+
+def known_shape_inputs(g, case):
+    """Inputs of a case, derived deterministically from the base fixture (shared with the tests)."""
+    num_iter, joints, weights, scale_fit, kid, init, final = KNOWN_SHAPE_CASES[case]
+    tv = g['kid.target_vertices'] if kid else g['target_vertices']
+    tj = g['kid.target_joints'] if kid else g['target_joints']
+    if scale_fit:  # a target that really is a scaled body
+        tv, tj = tv * np.float32(1.1), tj * np.float32(1.1)
+    kw = dict(num_iter=num_iter, final_adjust_rots=final, scale_fit=scale_fit)
+    kw['target_joints'] = tj if joints else None
+    kw['vertex_weights'] = g['vertex_weights'] if weights else None
+    kw['joint_weights'] = g['joint_weights'] if (weights and joints) else None
+    kw['kid_factor'] = g['kid'] if kid else None
+    if init:
+        rs = np.random.RandomState(99)
+        kw['initial_pose_rotvecs'] = (g['pose'] + rs.randn(*g['pose'].shape) * 0.05).astype(np.float32)
+    else:
+        kw['initial_pose_rotvecs'] = None
+    return g['betas'], tv, kw
+
+
+# case -> (joints, weights, scale)
+SCALE_TRANS_CASES = dict(a=(True, False, False), b=(True, True, True), c=(False, True, True),
+                         d=(False, False, True))
+
+
+def scale_trans_inputs(g):
+    tv, tj = g['target_vertices'], g['target_joints']
+    rv = np.ascontiguousarray(tv[::-1]) * np.float32(0.9) + np.float32(0.05)  # another body, scaled and shifted
+    rj = np.ascontiguousarray(tj[::-1]) * np.float32(0.9) + np.float32(0.05)
+    return tv, tj, rv, rj, g['vertex_weights'], g['joint_weights']
