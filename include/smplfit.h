@@ -133,6 +133,27 @@ int smplfit_forward_f32(const smplfit_handle* h, const float* pose_rotvecs,
                         float* orientations, void* workspace, size_t workspace_bytes,
                         void* hip_stream);
 
+/* BodyFitter.fit_with_known_shape (pt/bodyfitter.py:655-838): pose and translation (and, with
+ * scale_fit, one scale factor per instance) for KNOWN shape parameters.  num_iter rotation passes
+ * against the model posed at the current rotations, then fit_scale_and_translation (:1628-1681) and,
+ * with final_adjust_rots, the dependent refinement.
+ *   shape_betas (B,num_betas_given) -- betas beyond the handle's count are an error, missing ones are 0
+ *   kid_factor (B) or NULL          -- only on a handle created with enable_kid
+ *   initial_pose_rotvecs (B,3J) or NULL (rest pose)
+ *   target_* / *_weights            -- as smplfit_fit_f32
+ * Outputs: pose_rotvecs (B,3J), trans (B,3); scale_corr (B) is written only when scale_fit != 0;
+ * orientations / relative_orientations (B,J,3,3) may be NULL.
+ * The reference's scale branch multiplies a (B,) scale into (B,3) means and therefore only runs for
+ * B == 1 (:1675-1676); here every instance gets its own scale, which is what B == 1 calls return. */
+int smplfit_fit_known_shape_f32(const smplfit_handle* h, const float* shape_betas,
+                                int num_betas_given, const float* kid_factor,
+                                const float* initial_pose_rotvecs, const float* target_vertices,
+                                const float* target_joints, const float* vertex_weights,
+                                const float* joint_weights, int batch, int num_iter,
+                                int final_adjust_rots, int scale_fit, float* pose_rotvecs, float* trans,
+                                float* scale_corr, float* orientations, float* relative_orientations,
+                                void* workspace, size_t workspace_bytes, void* hip_stream);
+
 /* Stage entry points for parity tests. */
 
 /* First rotation pass of fit (pt/bodyfitter.py:384-394 -> _fit_global_rotations :1321-1416):

@@ -415,7 +415,8 @@ SF_HD void refine_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, co
                         const float* tj_in, const float* rj_joint_term, const float* rj_true,
                         const float* jw, const float* Gprev, const float* beta, const float* trans,
                         const float* mean, bool final_adjust, float* pose_out, float* beta_out,
-                        float* trans_out, float* kid_out, float* orient_out, float* rel_out) {
+                        float* trans_out, float* kid_out, float* orient_out, float* rel_out,
+                        const float* scale = nullptr) {
   const int J = tb.J, S = tb.S, S1 = S + 1;
   SF_FOR(k, J * 9) {
     sh.G[k] = Gprev[k];
@@ -429,6 +430,7 @@ SF_HD void refine_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, co
       float acc = 0.f;
       for (int s = 0; s < S; ++s) acc += tb.j_ext[k * S1 + 1 + s] * beta[s];
       sh.aux[k] = tb.j_ext[k * S1] + acc;
+      if (scale) sh.aux[k] *= scale[0];  // scale_corr of the known-shape fit (:1449-1450)
     }
     cx.sync();
     SF_FOR(k, J * 3) {  // bones (:1452-1460) into T (scratch), root position (:1481)
@@ -493,9 +495,100 @@ SF_HD void refine_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, co
     if (rel_out)
       for (int k = 0; k < 9; ++k) rel_out[j * 9 + k] = rel[k];
   }
-  SF_FOR(i, S - tb.n_kid) beta_out[i] = beta[i];
+  if (beta_out) SF_FOR(i, S - tb.n_kid) beta_out[i] = beta[i];
   if (tb.n_kid && kid_out && cx.lane == 0) kid_out[0] = beta[S - 1];
   SF_FOR(c, 3) trans_out[c] = trans[c] + mean[c];  // (:519)
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage A — scale and translation between the target and the posed reference
+//   fit_scale_and_translation, bodyfitter.py:1628-1681, as called by fit_with_known_shape (:764-772),
+//   followed by the substitution reference <- scale * reference + trans that the refinement is
+//   handed (:774-802), applied to the part sums and joints instead of re-skinning the mesh:
+//     raw' = s raw + s_t trans^T,  s_a' = s s_a + s_w trans,  joints' = s joints + trans.
+// Points: the V real vertices (SoA slots [0,V) of tvs / rverts, weights vws or null) and, when tj is
+// given, the J joints (weights jw or null).  The reference's per-instance scale (its (B,) * (B,3)
+// broadcast at :1675-1676 only runs for B == 1) is applied per instance.
+// red: cx.n * 8 floats of scratch.  rj_reg (regressed reference joints) may be null.
+// ---------------------------------------------------------------------------------------------
+template <class Ctx>
+SF_HD void scale_trans_stage(Ctx& cx, int J, int V, int Vp, float* red, const float* tvs,
+                             const float* rverts, const float* vws, const float* tj, float* rj,
+                             const float* jw, bool with_scale, float* psum, float* rj_reg,
+                             const float* reg_rowsum, float* trans_out, float* scale_out) {
+  // pass 1: weighted sums  [W, t(3), r(3)]
+  float a[7] = {0, 0, 0, 0, 0, 0, 0};
+  SF_FOR(i, V) {
+    const float w = vws ? vws[i] : 1.0f;
+    a[0] += w;
+    for (int c = 0; c < 3; ++c) {
+      a[1 + c] += w * tvs[c * Vp + i];
+      a[4 + c] += w * rverts[c * Vp + i];
+    }
+  }
+  if (tj) SF_FOR(j, J) {
+    const float w = jw ? jw[j] : 1.0f;
+    a[0] += w;
+    for (int c = 0; c < 3; ++c) {
+      a[1 + c] += w * tj[j * 3 + c];
+      a[4 + c] += w * rj[j * 3 + c];
+    }
+  }
+  for (int k = 0; k < 7; ++k) red[cx.lane * 8 + k] = a[k];
+  cx.sync();
+  float tot[7];
+  for (int k = 0; k < 7; ++k) {  // every lane sums the partials in the same order
+    float s = 0.f;
+    for (int l = 0; l < cx.n; ++l) s += red[l * 8 + k];
+    tot[k] = s;
+  }
+  cx.sync();
+  const float invW = 1.0f / tot[0];
+  const float mt[3] = {tot[1] * invW, tot[2] * invW, tot[3] * invW};
+  const float mr[3] = {tot[4] * invW, tot[5] * invW, tot[6] * invW};
+  float sc = 1.0f;
+  if (with_scale) {  // pass 2: centred second moments (:1665-1672)
+    float q[2] = {0, 0};
+    SF_FOR(i, V) {
+      const float w = vws ? vws[i] : 1.0f;
+      for (int c = 0; c < 3; ++c) {
+        const float dt = tvs[c * Vp + i] - mt[c], dr = rverts[c * Vp + i] - mr[c];
+        q[0] += w * dt * dt;
+        q[1] += w * dr * dr;
+      }
+    }
+    if (tj) SF_FOR(j, J) {
+      const float w = jw ? jw[j] : 1.0f;
+      for (int c = 0; c < 3; ++c) {
+        const float dt = tj[j * 3 + c] - mt[c], dr = rj[j * 3 + c] - mr[c];
+        q[0] += w * dt * dt;
+        q[1] += w * dr * dr;
+      }
+    }
+    red[cx.lane * 8] = q[0];
+    red[cx.lane * 8 + 1] = q[1];
+    cx.sync();
+    float st = 0.f, sr = 0.f;
+    for (int l = 0; l < cx.n; ++l) {
+      st += red[l * 8];
+      sr += red[l * 8 + 1];
+    }
+    cx.sync();
+    sc = sqrtf(st / sr);
+  }
+  const float tr[3] = {mt[0] - sc * mr[0], mt[1] - sc * mr[1], mt[2] - sc * mr[2]};
+  SF_FOR(j, J) {
+    float* ps = psum + j * kPsum;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) ps[r * 3 + c] = sc * ps[r * 3 + c] + ps[9 + r] * tr[c];
+    for (int c = 0; c < 3; ++c) {
+      ps[12 + c] = sc * ps[12 + c] + ps[15] * tr[c];
+      rj[j * 3 + c] = sc * rj[j * 3 + c] + tr[c];
+      if (rj_reg) rj_reg[j * 3 + c] = sc * rj_reg[j * 3 + c] + reg_rowsum[j] * tr[c];
+    }
+  }
+  SF_FOR(c, 3) trans_out[c] = tr[c];
+  if (cx.lane == 0 && scale_out) scale_out[0] = sc;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -420,6 +420,7 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
   t.reg_start.assign(1, 0);
   t.reg_slot.clear();
   t.reg_val.clear();
+  t.reg_rowsum.assign(J, 0.f);
   if (d.J_regressor_post_lbs && d.regressor_num_vertices == V) {
     std::vector<int> slot_of(V);
     for (int i = 0; i < V; ++i) slot_of[order[i]] = i;
@@ -433,6 +434,7 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
       for (auto& e : row) {
         t.reg_slot.push_back(e.first);
         t.reg_val.push_back(e.second);
+        t.reg_rowsum[j] += e.second;
       }
       t.reg_start.push_back((int)t.reg_slot.size());
     }

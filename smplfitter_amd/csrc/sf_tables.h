@@ -96,6 +96,7 @@ struct HostTables {
   // sparse post-LBS joint regressor, CSR over sorted slots (joints-omitted path)
   std::vector<int32_t> reg_start, reg_slot;
   std::vector<float> reg_val;
+  std::vector<float> reg_rowsum;  // (J) sum of each regressor row (regressed joints of a translated mesh)
 
   int num_levels() const { return (int)fk_level_start.size() - 1; }
   // floats per vertex in cpack: multiple of 4 (16-B rows) and = 4 (mod 8) so that 16 consecutive

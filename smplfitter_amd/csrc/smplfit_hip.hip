@@ -59,6 +59,7 @@ struct DevModel {
   const uint32_t* widx;
   const int32_t *reg_start, *reg_slot;
   const float* reg_val;
+  const float* reg_rowsum;
 };
 
 }  // namespace
@@ -128,6 +129,7 @@ struct Workspace {
   float* tjreg;    // (B,J,3) regressed target joints (joints-omitted path)
   float* rjreg;    // (B,J,3) regressed reference joints
   float* mbj;      // (B,J,3) per-joint residual moments (pair-Gram form)
+  float* scale;    // (B) scale_corr of the known-shape fit
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -162,6 +164,7 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w) {
   ws.tjreg = (float*)take((size_t)B * J * 3 * 4);
   ws.rjreg = (float*)take((size_t)B * J * 3 * 4);
   ws.mbj = (float*)take((size_t)B * J * 3 * 4);
+  ws.scale = (float*)take((size_t)B * 4);
   if (w) *w = ws;
   return off;
 }
@@ -1046,6 +1049,7 @@ struct RefineArgs {
   const float* jw;        // (B,J) or null
   int final_adjust;
   float *pose, *betas, *trans, *kid, *orient, *rel;
+  int scaled;  // known-shape fit with scale_fit: rest joints are scaled by ws.scale
 };
 
 __global__ __launch_bounds__(64) void k_refine_epilogue(DevModel m, RefineArgs a, Workspace ws) {
@@ -1058,9 +1062,44 @@ __global__ __launch_bounds__(64) void k_refine_epilogue(DevModel m, RefineArgs a
                    a.jw ? a.jw + (size_t)b * J : nullptr, ws.G + (size_t)b * J * 9,
                    ws.beta + (size_t)b * S, ws.trans + (size_t)b * 3, ws.mean + (size_t)b * 3,
                    a.final_adjust != 0, a.pose + (size_t)b * J * 3,
-                   a.betas + (size_t)b * (S - m.jt.n_kid), a.trans + (size_t)b * 3,
+                   a.betas ? a.betas + (size_t)b * (S - m.jt.n_kid) : nullptr, a.trans + (size_t)b * 3,
                    a.kid ? a.kid + b : nullptr, a.orient ? a.orient + (size_t)b * J * 9 : nullptr,
-                   a.rel ? a.rel + (size_t)b * J * 9 : nullptr);
+                   a.rel ? a.rel + (size_t)b * J * 9 : nullptr, a.scaled ? ws.scale + b : nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// known-shape fit: the given shape (betas [+ kid]) to the workspace layout, zero translation
+// ------------------------------------------------------------------------------------------------
+__global__ void k_fill_shape(Workspace ws, int B, int S, int n_kid, const float* __restrict__ betas,
+                             int nb, const float* __restrict__ kid) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  for (int s = 0; s < S - n_kid; ++s) ws.beta[(size_t)b * S + s] = s < nb ? betas[(size_t)b * nb + s] : 0.f;
+  if (n_kid) ws.beta[(size_t)b * S + S - 1] = kid ? kid[b] : 0.f;
+  for (int c = 0; c < 3; ++c) ws.trans[b * 3 + c] = 0.f;
+}
+
+// known-shape fit: scale + translation of the posed reference onto the target, folded into the part
+// sums and joints the refinement reads (sf::scale_trans_stage).  grid B, block 256.
+struct ScaleTransArgs {
+  const float* tj;   // (B,J,3) centred target joints or null (vertices only)
+  const float* jw;   // (B,J) or null
+  int weighted_v, with_scale, regressed;
+  float* scale_out;  // (B) or null
+};
+
+__global__ __launch_bounds__(256) void k_scale_trans(DevModel m, ScaleTransArgs a, Workspace ws) {
+  __shared__ float red[256 * 8];
+  const int b = blockIdx.x, J = m.J, Vp = m.Vp;
+  DevCtx cx{(int)threadIdx.x, 256};
+  sf::scale_trans_stage(cx, J, m.V, Vp, red, ws.tvs + (size_t)b * 3 * Vp, ws.rverts + (size_t)b * 3 * Vp,
+                        a.weighted_v ? ws.vws + (size_t)b * Vp : nullptr,
+                        a.tj ? a.tj + (size_t)b * J * 3 : nullptr, ws.rjoints + (size_t)b * J * 3,
+                        a.jw ? a.jw + (size_t)b * J : nullptr, a.with_scale != 0,
+                        ws.psum + (size_t)b * J * sf::kPsum,
+                        a.regressed ? ws.rjreg + (size_t)b * J * 3 : nullptr, m.reg_rowsum,
+                        ws.trans + (size_t)b * 3, ws.scale + b);
+  if (a.scale_out && threadIdx.x == 0) a.scale_out[b] = ws.scale[b];  // written by this lane above
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1340,6 +1379,86 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   return post_launch_check();
 }
 
+// fit_with_known_shape (bodyfitter.py:655-838): pose and translation (optionally a scale) for given
+// shape parameters.  Alternates the LBS forward at the current rotations (forward joint stage, GEMM,
+// K5 with the part sums against the target) with the part-rotation stage; then the alignment stage
+// and the dependent refinement.  num_iter rotation passes, num_iter + 1 forward passes.
+struct KnownShapeOptions {
+  int num_iter, final_adjust, scale_fit;
+};
+
+int run_fit_known_shape(const smplfit_handle* h, const float* betas, int nb, const float* kid,
+                        const float* init_pose, const float* tv, const float* tj, const float* vw,
+                        const float* jw, int B, const KnownShapeOptions& o, float* pose, float* trans,
+                        float* scale_out, float* orient, float* rel, const Workspace& ws, hipStream_t st) {
+  const DevModel& d = h->d;
+  const bool joints = tj != nullptr;
+  if (!joints && !h->t.has_regressor)
+    return fail(SMPLFIT_ERR_BAD_ARG,
+                "target_joints omitted but the model has no J_regressor_post_lbs over its vertices");
+  const bool vweighted = vw != nullptr;
+  launch_center_sort(d, tv, tj, vw, ws, B, st);
+  const float* tj_rot = ws.tjc;
+  if (!joints) {
+    hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(64), 0, st, d, ws.tvs, ws.tjreg);
+    tj_rot = ws.tjreg;
+  }
+  hipLaunchKernelGGL(k_fill_shape, dim3((B + 255) / 256), dim3(256), 0, st, ws, B, d.S, d.jt.n_kid, betas,
+                     std::min(nb, d.S - d.jt.n_kid), kid);
+  ForwardArgs fa{};
+  fa.pose = init_pose;  // null -> rest pose
+  fa.betas = ws.beta;   // (B,S) incl. the kid column: j_ext's last column is kid_J_shapedir
+  fa.nb = d.S;
+  fa.joints = ws.rjoints;
+  fa.orient = ws.G;
+  JointStageArgs ja{};
+  ja.tj = tj_rot;
+  ja.jw = jw;
+  ja.fit_rotations = 1;
+  ja.do_prologue = 0;
+  ja.rj_shared = 0;
+  ja.Gprev = ws.G;
+  for (int it = 0; it <= o.num_iter; ++it) {
+    hipLaunchKernelGGL(k_forward_joint, dim3(B), dim3(64), joint_lds(d), st, d, fa, ws);
+    launch_gemm(d, ws, B, st);
+    // MODE 1: the posed mesh is kept (regressed joints, alignment sums) next to the part sums
+#define SF_CALL_LBS(S_, KW_) \
+  launch_lbs<S_, KW_, 1, false>(d, ws, B, vweighted, d.S, ws.beta, ws.trans, nullptr, 0.f, 0.f, st)
+    SF_DISPATCH_SKW(d, SF_CALL_LBS);
+#undef SF_CALL_LBS
+    if (!joints)
+      hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(64), 0, st, d, ws.rverts, ws.rjreg);
+    if (it == o.num_iter) break;
+    ja.rj = joints ? ws.rjoints : ws.rjreg;
+    hipLaunchKernelGGL(k_joint_stage, dim3(B), dim3(64), joint_lds(d), st, d, ja, ws);
+    fa.pose = nullptr;
+    fa.glob = ws.G;
+  }
+  ScaleTransArgs sa{};
+  sa.tj = joints ? ws.tjc : nullptr;
+  // weights enter only if both are given (with joints) / vertex weights alone without joints (:1640-1661)
+  sa.weighted_v = joints ? (vw && jw) : (vw != nullptr);
+  sa.jw = (joints && vw && jw) ? jw : nullptr;
+  sa.with_scale = o.scale_fit;
+  sa.regressed = joints ? 0 : 1;
+  sa.scale_out = o.scale_fit ? scale_out : nullptr;
+  hipLaunchKernelGGL(k_scale_trans, dim3(B), dim3(256), 0, st, d, sa, ws);
+  RefineArgs ra{};
+  ra.tj = tj_rot;
+  ra.rj_term = joints ? ws.rjoints : ws.rjreg;
+  ra.jw = jw;
+  ra.final_adjust = o.final_adjust;
+  ra.pose = pose;
+  ra.betas = nullptr;
+  ra.trans = trans;
+  ra.kid = nullptr;
+  ra.orient = orient;
+  ra.rel = rel;
+  ra.scaled = o.scale_fit;
+  hipLaunchKernelGGL(k_refine_epilogue, dim3(B), dim3(64), joint_lds(d, 1), st, d, ra, ws);
+  return post_launch_check();
+}
+
 template <typename T>
 int upload(smplfit_handle* h, const std::vector<T>& src, const T** dst) {
   void* p = nullptr;
@@ -1463,6 +1582,7 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
   up(t.reg_start, &d.reg_start);
   up(t.reg_slot, &d.reg_slot);
   up(t.reg_val, &d.reg_val);
+  up(t.reg_rowsum, &d.reg_rowsum);
   sf::JointTabs& jt = d.jt;
   jt.J = t.J; jt.S = t.S; jt.num_levels = t.num_levels(); jt.adj_last_level = t.adj_last_level;
   jt.P = t.P; jt.Kp = t.Kp;
@@ -1626,6 +1746,35 @@ int smplfit_fit_f32(const smplfit_handle* h, const float* target_vertices,
     b0 += sizes[c];
   }
   return SMPLFIT_OK;
+}
+
+int smplfit_fit_known_shape_f32(const smplfit_handle* h, const float* shape_betas,
+                                int num_betas_given, const float* kid_factor,
+                                const float* initial_pose_rotvecs, const float* target_vertices,
+                                const float* target_joints, const float* vertex_weights,
+                                const float* joint_weights, int batch, int num_iter,
+                                int final_adjust_rots, int scale_fit, float* pose_rotvecs, float* trans,
+                                float* scale_corr, float* orientations, float* relative_orientations,
+                                void* workspace, size_t workspace_bytes, void* hip_stream) {
+  int rc = check_common(h, batch, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (!shape_betas || !target_vertices || !pose_rotvecs || !trans)
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_known_shape_f32: null input/output pointer");
+  if (num_iter < 1) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_known_shape_f32: num_iter must be >= 1");
+  if (scale_fit && !scale_corr)
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_known_shape_f32: scale_fit needs the scale_corr output");
+  const sf::HostTables& t = h->t;
+  if (kid_factor && !t.n_kid)
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_known_shape_f32: kid_factor given to a handle without kid");
+  if (num_betas_given < 0 || num_betas_given > t.S - t.n_kid)
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_known_shape_f32: more betas than the model holds; slice first");
+  KnownShapeOptions o{num_iter, final_adjust_rots ? 1 : 0, scale_fit ? 1 : 0};
+  hipStream_t st = (hipStream_t)hip_stream;
+  Workspace ws;
+  carve(t, batch, (char*)workspace, &ws);
+  return run_fit_known_shape(h, shape_betas, num_betas_given, kid_factor, initial_pose_rotvecs,
+                             target_vertices, target_joints, vertex_weights, joint_weights, batch, o,
+                             pose_rotvecs, trans, scale_corr, orientations, relative_orientations, ws, st);
 }
 
 int smplfit_part_rotations_f32(const smplfit_handle* h, const float* target_vertices,

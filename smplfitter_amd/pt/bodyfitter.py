@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -162,8 +163,72 @@ class BodyFitter(nn.Module):
             out['kid_factor'] = r['kid_factor']
         return out
 
-    def fit_with_known_shape(self, *args, **kwargs):
-        raise NotImplementedError('fit_with_known_shape is not implemented yet (pt/bodyfitter.py:656-838)')
+    def fit_with_known_shape(
+        self,
+        shape_betas: torch.Tensor,
+        target_vertices: torch.Tensor,
+        target_joints: Optional[torch.Tensor] = None,
+        vertex_weights: Optional[torch.Tensor] = None,
+        joint_weights: Optional[torch.Tensor] = None,
+        kid_factor: Optional[torch.Tensor] = None,
+        num_iter: int = 1,
+        final_adjust_rots: bool = True,
+        initial_pose_rotvecs: Optional[torch.Tensor] = None,
+        scale_fit: bool = False,
+        requested_keys: Optional[list[str]] = None,
+    ) -> dict[str, torch.Tensor]:
+        """Pose and translation (and, with ``scale_fit``, a per-instance scale) for known shape
+        parameters (reference pt/bodyfitter.py:655-838), one C-ABI call
+        (``smplfit_fit_known_shape_f32``).  Result keys as the reference: ``trans``, ``orientations``,
+        ``scale_corr`` with ``scale_fit``, ``relative_orientations`` / ``pose_rotvecs`` when requested.
+
+        The reference's ``scale_fit`` branch only runs for a batch of one (a ``(B,)`` scale is multiplied
+        into ``(B,3)`` means, :1675-1676); here every instance gets the scale a batch-of-one call gives."""
+        if requested_keys is None:
+            requested_keys = ['pose_rotvecs']
+        bm = self.body_model
+        device = bm.v_template.device
+        for name, arg in (('target_vertices', target_vertices), ('shape_betas', shape_betas)):
+            if isinstance(arg, np.ndarray):
+                raise TypeError(f"Expected torch.Tensor for '{name}', got numpy.ndarray.")
+        if target_vertices.ndim != 3:
+            raise ValueError(f'Expected batched target_vertices (B, V, 3), got {tuple(target_vertices.shape)}')
+        if any(t is not None and t.requires_grad for t in
+               (shape_betas, target_vertices, target_joints, initial_pose_rotvecs)):
+            raise NotImplementedError('the HIP path is not differentiable')
+        prep = lambda t: None if t is None else t.to(device=device, dtype=torch.float32).contiguous()  # noqa: E731
+        tv, tj, vw, jw = prep(target_vertices), prep(target_joints), prep(vertex_weights), prep(joint_weights)
+        B, J = tv.shape[0], bm.num_joints
+        betas = prep(shape_betas)[:, :bm.num_betas].contiguous()
+        kid = None
+        if kid_factor is not None:
+            kid = torch.as_tensor(kid_factor, dtype=torch.float32, device=device).reshape(-1)
+            kid = kid.expand(B).contiguous() if kid.numel() == 1 else kid.contiguous()
+        init = None if initial_pose_rotvecs is None else prep(initial_pose_rotvecs.reshape(B, J * 3))
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)  # noqa: E731
+        pose, trans = new(B, J * 3), new(B, 3)
+        orient, rel = new(B, J, 3, 3), new(B, J, 3, 3)
+        scale = new(B) if scale_fit else None
+        if B == 0:
+            out = dict(trans=trans, orientations=orient)
+        else:
+            h = bm._native(device, kid=kid is not None)
+            ws = bm._workspace(h, B, device)
+            with torch.cuda.device(device):
+                stream = torch.cuda.current_stream(device).cuda_stream
+                _lib.check(_lib.load().smplfit_fit_known_shape_f32(
+                    h.ptr, _ptr(betas), betas.shape[1], _ptr(kid), _ptr(init), _ptr(tv), _ptr(tj), _ptr(vw),
+                    _ptr(jw), B, int(num_iter), int(bool(final_adjust_rots)), int(bool(scale_fit)),
+                    _ptr(pose), _ptr(trans), _ptr(scale), _ptr(orient), _ptr(rel), _ptr(ws), ws.numel(),
+                    C.c_void_p(stream)))
+            out = dict(trans=trans, orientations=orient)
+        if scale_fit:
+            out['scale_corr'] = scale
+        if 'relative_orientations' in requested_keys or 'pose_rotvecs' in requested_keys:
+            out['relative_orientations'] = rel
+        if 'pose_rotvecs' in requested_keys:
+            out['pose_rotvecs'] = pose
+        return out
 
     # -- stage entry points, used by the parity tests ---------------------------------------------
     def _part_rotations(self, target_vertices, target_joints=None, vertex_weights=None, joint_weights=None):

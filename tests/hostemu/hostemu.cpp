@@ -316,6 +316,72 @@ int fit_impl(const sf::HostTables& t, const float* tv, const float* tj, const fl
   return 0;
 }
 
+// mirrors run_fit_known_shape (smplfit_hip.hip)
+template <int S, int KW>
+int known_shape_impl(const sf::HostTables& t, const float* betas, int nb, const float* kid,
+                     const float* init_pose, const float* tv, const float* tj, const float* vw,
+                     const float* jw, int B, int num_iter, int final_adjust, int scale_fit, float* pose,
+                     float* trans, float* scale_out, float* orient) {
+  Emu<S, KW> e(t, B);
+  const bool joints = tj != nullptr;
+  if (!joints && !t.has_regressor) { g_err = "no regressor"; return -1; }
+  e.k0(tv, tj, vw);
+  const float* tj_rot = e.tjc.data();
+  if (!joints) {
+    e.regress(e.tvs.data(), false, e.tjreg.data(), B);
+    tj_rot = e.tjreg.data();
+  }
+  const int nbe = std::min(nb, S - t.n_kid);
+  for (int b = 0; b < B; ++b) {
+    for (int s = 0; s < S - t.n_kid; ++s) e.beta[(size_t)b * S + s] = s < nbe ? betas[(size_t)b * nb + s] : 0.f;
+    if (t.n_kid) e.beta[(size_t)b * S + S - 1] = kid ? kid[b] : 0.f;
+    for (int c = 0; c < 3; ++c) e.trans[(size_t)b * 3 + c] = 0.f;
+  }
+  HostCtx cx;
+  std::vector<float> scale((size_t)B, 1.f);
+  for (int it = 0; it <= num_iter; ++it) {
+    for (int b = 0; b < B; ++b) {
+      std::vector<float> Gin(e.G.begin() + (size_t)b * t.J * 9, e.G.begin() + (size_t)(b + 1) * t.J * 9);
+      sf::forward_joint_stage(cx, e.jt, e.sh, (it == 0 && init_pose) ? init_pose + (size_t)b * t.J * 3 : nullptr,
+                              it == 0 ? nullptr : Gin.data(), e.beta.data() + (size_t)b * S, S, nullptr,
+                              nullptr, e.rp.data() + (size_t)b * t.Kp, e.jd_b(b),
+                              e.rjoints.data() + (size_t)b * t.J * 3, e.G.data() + (size_t)b * t.J * 9);
+      for (int k = 0; k < t.J * 3; ++k)
+        e.jb[(size_t)b * t.J * 4 + (k / 3) * 4 + k % 3] = e.jd_b(b)[(k / 3) * sf::jd_stride(S) + 9 + k % 3];
+    }
+    e.gemm();
+    e.k5(vw != nullptr, true);
+    if (!joints) e.regress(e.rverts.data(), false, e.rjreg.data(), B);
+    if (it == num_iter) break;
+    std::vector<float> Gprev = e.G;
+    e.k1(tj_rot, joints ? e.rjoints.data() : e.rjreg.data(), false, Gprev.data(), jw, true, false, false,
+         false, false);
+  }
+  const bool wv = joints ? (vw && jw) : (vw != nullptr);
+  const float* jwe = (joints && vw && jw) ? jw : nullptr;
+  std::vector<float> red(8);
+  for (int b = 0; b < B; ++b) {
+    sf::scale_trans_stage(cx, t.J, t.V, t.Vp, red.data(), e.tvs.data() + (size_t)b * 3 * t.Vp,
+                          e.rverts.data() + (size_t)b * 3 * t.Vp, wv ? e.vws.data() + (size_t)b * t.Vp : nullptr,
+                          joints ? e.tjc.data() + (size_t)b * t.J * 3 : nullptr,
+                          e.rjoints.data() + (size_t)b * t.J * 3, jwe ? jwe + (size_t)b * t.J : nullptr,
+                          scale_fit != 0, e.psum.data() + (size_t)b * t.J * sf::kPsum,
+                          joints ? nullptr : e.rjreg.data() + (size_t)b * t.J * 3, t.reg_rowsum.data(),
+                          e.trans.data() + (size_t)b * 3, scale.data() + b);
+    if (scale_fit && scale_out) scale_out[b] = scale[b];
+    sf::refine_stage(cx, e.jt, e.sh, e.psum.data() + (size_t)b * t.J * sf::kPsum,
+                     tj_rot + (size_t)b * t.J * 3,
+                     (joints ? e.rjoints.data() : e.rjreg.data()) + (size_t)b * t.J * 3,
+                     e.rjoints.data() + (size_t)b * t.J * 3, jw ? jw + (size_t)b * t.J : nullptr,
+                     e.G.data() + (size_t)b * t.J * 9, e.beta.data() + (size_t)b * S,
+                     e.trans.data() + (size_t)b * 3, e.mean.data() + (size_t)b * 3, final_adjust != 0,
+                     pose + (size_t)b * t.J * 3, nullptr, trans + (size_t)b * 3, nullptr,
+                     orient ? orient + (size_t)b * t.J * 9 : nullptr, nullptr,
+                     scale_fit ? scale.data() + b : nullptr);
+  }
+  return 0;
+}
+
 template <int S, int KW>
 int forward_impl(const sf::HostTables& t, const float* pose, const float* glob, const float* betas,
                  int nb, const float* trans, const float* kid, int B, float* verts, float* joints,
@@ -376,6 +442,23 @@ int hostemu_fit(const smplfit_model_desc* d, const float* tv, const float* tj, c
     return fit_impl<16, 4>(t, tv, tj, vw, jw, B, num_iter, reg, reg2, kid_reg, final_adjust, pose, betas, trans, kid, orient, G0_out);
   if (t.S == 11 && t.KW == 4)
     return fit_impl<11, 4>(t, tv, tj, vw, jw, B, num_iter, reg, reg2, kid_reg, final_adjust, pose, betas, trans, kid, orient, G0_out);
+  g_err = "hostemu: unsupported (S, KW)";
+  return -2;
+}
+
+int hostemu_fit_known_shape(const smplfit_model_desc* d, const float* betas, int nb, const float* kid,
+                            const float* init_pose, const float* tv, const float* tj, const float* vw,
+                            const float* jw, int B, int num_iter, int final_adjust, int scale_fit,
+                            float* pose, float* trans, float* scale_out, float* orient) {
+  sf::HostTables t;
+  bool unsup = false;
+  g_err = sf::build_tables(*d, t, &unsup);
+  if (!g_err.empty()) return -1;
+#define HE_KS(S_, KW_) \
+  if (t.S == S_ && t.KW == KW_) \
+    return known_shape_impl<S_, KW_>(t, betas, nb, kid, init_pose, tv, tj, vw, jw, B, num_iter, final_adjust, scale_fit, pose, trans, scale_out, orient)
+  HE_KS(10, 4); HE_KS(10, 8); HE_KS(16, 4); HE_KS(11, 4);
+#undef HE_KS
   g_err = "hostemu: unsupported (S, KW)";
   return -2;
 }

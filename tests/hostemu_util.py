@@ -38,6 +38,8 @@ def load():
     lib.hostemu_fit.restype = i32
     lib.hostemu_forward.argtypes = [C.POINTER(_lib.ModelDesc), vp, vp, vp, i32, vp, vp, i32, vp, vp, vp]
     lib.hostemu_forward.restype = i32
+    lib.hostemu_fit_known_shape.argtypes = [C.POINTER(_lib.ModelDesc), vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
+    lib.hostemu_fit_known_shape.restype = i32
     lib.hostemu_last_error.restype = C.c_char_p
     for fn in ('hostemu_proj_so3', 'hostemu_mat2rotvec', 'hostemu_rotvec2mat'):
         getattr(lib, fn).argtypes = [vp, vp, i32]
@@ -102,3 +104,27 @@ def forward(md, kind, pose=None, betas=None, trans=None, glob=None, kid=None):
     if rc != 0:
         raise RuntimeError(lib.hostemu_last_error().decode())
     return dict(vertices=verts, joints=joints, orientations=orient)
+
+
+def fit_known_shape(md, kind, betas, tv, target_joints=None, vertex_weights=None, joint_weights=None,
+                    kid_factor=None, num_iter=1, final_adjust_rots=True, initial_pose_rotvecs=None,
+                    scale_fit=False):
+    lib = load()
+    desc, keep = desc_from_md(md, kind, kid_factor is not None)
+    f = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)  # noqa: E731
+    betas, tv, tj, vw, jw = f(betas), f(tv), f(target_joints), f(vertex_weights), f(joint_weights)
+    kid, init = f(kid_factor), f(initial_pose_rotvecs)
+    B, J = tv.shape[0], md.num_joints
+    pose = np.zeros((B, 3 * J), np.float32)
+    trans = np.zeros((B, 3), np.float32)
+    scale = np.ones((B,), np.float32)
+    orient = np.zeros((B, J, 3, 3), np.float32)
+    rc = lib.hostemu_fit_known_shape(C.byref(desc), _p(betas), betas.shape[1], _p(kid), _p(init), _p(tv),
+                                     _p(tj), _p(vw), _p(jw), B, num_iter, int(final_adjust_rots),
+                                     int(scale_fit), _p(pose), _p(trans), _p(scale), _p(orient))
+    if rc != 0:
+        raise RuntimeError(lib.hostemu_last_error().decode())
+    out = dict(pose_rotvecs=pose, trans=trans, orientations=orient)
+    if scale_fit:
+        out['scale_corr'] = scale
+    return out

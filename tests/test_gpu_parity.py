@@ -303,3 +303,57 @@ def test_convert_vertices_sparse(model_root, golden, dev, tmp_path, monkeypatch)
     out = conv.convert_vertices(v).cpu().numpy()
     ref = np.einsum('ov,bvc->boc', mat.toarray(), g['target_vertices'])
     assert out.shape == (4, 10475, 3) and np.abs(out - ref).max() < 1e-5
+
+
+@pytest.mark.parametrize('name', ['smpl', 'smplx'])
+def test_known_shape_goldens(name, model_root, golden, dev):
+    """BodyFitter.fit_with_known_shape (smplfit_fit_known_shape_f32) against the reference's fixture:
+    num_iter 1..3, joints given / omitted, weights, scale_fit, kid_factor, warm start, no final adjust."""
+    g, ge = golden(name), golden(f'ext_{name}')
+    kind, md = util.load_md(model_root, name, g)
+    om, _ = util.make_oracle(md, kind, np.float64)
+    m, f = get_model(model_root, name, g, dev)
+    for case in util.KNOWN_SHAPE_CASES:
+        if f'knownshape.{case}.trans' not in ge:
+            continue
+        betas, tv, kw = util.known_shape_inputs(g, case)
+        kwt = {k: (t(v, dev) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+        r = f.fit_with_known_shape(t(betas, dev), t(tv, dev), requested_keys=['pose_rotvecs'], **kwt)
+        assert ('scale_corr' in r) == bool(kw['scale_fit'])
+        o = to_np(r)
+        util.check_known_shape(om, name, case, o, ge, betas, kw)
+        # relative orientations are consistent with the global ones
+        G, rel = o['orientations'], o['relative_orientations']
+        par = md.kintree_parents
+        for j in range(1, md.num_joints):
+            assert np.abs(np.swapaxes(G[:, par[j]], -1, -2) @ G[:, j] - rel[:, j]).max() < 1e-5
+
+
+def test_known_shape_vs_oracle_and_roundtrip(model_root, golden, dev):
+    """Known-shape fit on a fresh seeded batch: agreement with the CPU oracle, and the round trip
+    forward(pose, betas, trans) -> fit_with_known_shape(betas) reproduces the mesh."""
+    g = golden('smpl')
+    kind, md = util.load_md(model_root, 'smpl', g)
+    om, of = util.make_oracle(md, kind)
+    m, f = get_model(model_root, 'smpl', g, dev)
+    B = 48
+    rs = np.random.RandomState(5)
+    pose = (rs.randn(B, 72) * 0.15).astype(np.float32)
+    betas = (rs.randn(B, 10) * 0.7).astype(np.float32)
+    trans = rs.randn(B, 3).astype(np.float32)
+    fw = om.forward(pose, betas, trans)
+    tv = fw['vertices'] + (rs.randn(*fw['vertices'].shape) * 0.003).astype(np.float32)
+    tj = fw['joints']
+    for kw in (dict(num_iter=2), dict(num_iter=2, scale_fit=True), dict(num_iter=1, use_joints=False)):
+        kw = dict(kw)
+        uj = kw.pop('use_joints', True)
+        r = to_np(f.fit_with_known_shape(t(betas, dev), t(tv, dev), t(tj, dev) if uj else None, **kw))
+        o = of.fit_with_known_shape(betas, tv, tj if uj else None, **kw)
+        assert np.abs(r['trans'] - o['trans']).max() < 2e-5
+        va = om.forward(r['pose_rotvecs'], betas, r['trans'])['vertices']
+        vb = om.forward(o['pose_rotvecs'], betas, o['trans'])['vertices']
+        assert np.linalg.norm(va - vb, axis=-1).max() < 1e-4
+        if kw.get('scale_fit'):
+            assert np.abs(r['scale_corr'] - o['scale_corr']).max() < 1e-5
+        else:  # 3 mm of noise: the fitted mesh is within a few mm of the clean one
+            assert np.linalg.norm(va - fw['vertices'], axis=-1).mean() < 5e-3

@@ -104,3 +104,18 @@ def test_kid_goldens(name, model_root, golden):
         assert np.abs(o['shape_betas'] - ref['shape_betas']).max() < 1e-3, tag
         assert np.abs(o['kid_factor'] - ref['kid_factor']).max() < 1e-3, tag
         assert np.abs(o['trans'] - ref['trans']).max() < 2e-5, tag
+
+
+@pytest.mark.parametrize('name', ['smpl', 'smplx'])
+def test_known_shape_goldens(name, model_root, golden):
+    """fit_with_known_shape through the shared stage code (forward joint stage, part rotations,
+    scale/translation alignment, refinement) against the reference's fixture."""
+    g, ge = golden(name), golden(f'ext_{name}')
+    kind, md = util.load_md(model_root, name, g)
+    om, _ = util.make_oracle(md, kind, np.float64)
+    for case in util.KNOWN_SHAPE_CASES:
+        if f'knownshape.{case}.trans' not in ge:
+            continue
+        betas, tv, kw = util.known_shape_inputs(g, case)
+        o = H.fit_known_shape(md, kind, betas, tv, **kw)
+        util.check_known_shape(om, name, case, o, ge, betas, kw)

@@ -86,3 +86,17 @@ def scale_trans_inputs(g):
     rv = np.ascontiguousarray(tv[::-1]) * np.float32(0.9) + np.float32(0.05)  # another body, scaled and shifted
     rj = np.ascontiguousarray(tj[::-1]) * np.float32(0.9) + np.float32(0.05)
     return tv, tj, rv, rj, g['vertex_weights'], g['joint_weights']
+
+
+def check_known_shape(om, name, case, o, ge, betas, kw):
+    """Shared assertions of the known-shape fit against the reference's fixture (golden_ext_*.npz):
+    the mesh posed with the result is the gate (1e-4 m)."""
+    ref = {k: ge[f'knownshape.{case}.{k}'] for k in ('pose_rotvecs', 'trans', 'orientations')}
+    assert np.abs(o['trans'] - ref['trans']).max() < 2e-5, case
+    assert np.abs(o['orientations'] - ref['orientations']).max() < (1.5e-3 if name == 'smpl' else 5e-3), case
+    if kw['scale_fit']:
+        assert np.abs(o['scale_corr'] - ge[f'knownshape.{case}.scale_corr'].reshape(-1)).max() < 1e-5, case
+    kid = kw['kid_factor']
+    va = om.forward(o['pose_rotvecs'], betas, o['trans'], kid_factor=kid)['vertices']
+    vb = om.forward(ref['pose_rotvecs'], betas, ref['trans'], kid_factor=kid)['vertices']
+    assert np.linalg.norm(va - vb, axis=-1).max() < 1e-4, case
