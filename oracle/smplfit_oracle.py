@@ -319,7 +319,9 @@ class OracleFitter:
         return R
 
     # -- shape solve (pt/bodyfitter.py:840-1102) --------------------------------------------------
-    def fit_shape(self, G, tv, tj, vw, jw, beta_reg, beta_reg2, kid_reg=None):
+    def fit_shape(self, G, tv, tj, vw, jw, beta_reg, beta_reg2, kid_reg=None, reg_ref=None):
+        """``reg_ref`` (B, S_all): values the ridge pulls towards (beta/kid_regularizer_reference,
+        :1072-1081, :1224-1255); zeros when None."""
         m, dt, J, S, par = self.m, self.m.dtype, self.m.J, self.S_all, self.m.parents
         B = tv.shape[0]
         Gpar = np.concatenate([np.broadcast_to(np.eye(3, dtype=dt), (B, 1, 3, 3)), G[:, par[1:]]], 1)
@@ -377,6 +379,8 @@ class OracleFitter:
         lam = np.concatenate([np.full(2, float(beta_reg2)), np.full(n_plain - 2, float(beta_reg))])
         if self.enable_kid:  # kid_regularizer defaults to beta_regularizer (pt/bodyfitter.py:1235-1242)
             lam = np.concatenate([lam, [float(beta_reg if kid_reg is None else kid_reg)]])
+        if reg_ref is not None:
+            rhs_c = rhs_c + (lam[None] * np.asarray(reg_ref, np.float64))[..., None]
         x = np.linalg.solve(gram_c + np.diag(lam), rhs_c)  # SPD; reference uses Cholesky (:1083-1084)
         trans = (sb / Ws - (sA / Ws) @ x)[..., 0].astype(dt)
         beta = x[..., 0].astype(dt)
@@ -436,7 +440,8 @@ class OracleFitter:
     # -- driver (pt/bodyfitter.py:283-549) ----------------------------------------------------------
     def fit(self, target_vertices, target_joints=None, vertex_weights=None, joint_weights=None,
             num_iter=1, beta_regularizer=1.0, beta_regularizer2=0.0, final_adjust_rots=True,
-            return_stages=False, kid_regularizer=None):
+            return_stages=False, kid_regularizer=None, initial_pose_rotvecs=None,
+            initial_shape_betas=None, initial_kid_factor=None):
         m, dt, J, par = self.m, self.m.dtype, self.m.J, self.m.parents
         tv = np.asarray(target_vertices, dt)
         tj = None if target_joints is None else np.asarray(target_joints, dt)
@@ -451,16 +456,32 @@ class OracleFitter:
             tv = tv - mean[:, None]
             tj = tj - mean[:, None]
         stages = {}
-        G = self.fit_global_rotations(tv, tj, self.default_mesh[None], m.J_template[None], vw, jw)
+        reg_ref = None
+        if initial_pose_rotvecs is not None or initial_shape_betas is not None:  # warm start (:363-382)
+            pose0 = (np.zeros((B, 3 * J), dt) if initial_pose_rotvecs is None
+                     else np.asarray(initial_pose_rotvecs, dt))
+            f = m.forward(pose_rotvecs=pose0, shape_betas=initial_shape_betas, kid_factor=initial_kid_factor)
+            G = self.fit_global_rotations(tv, tj, f['vertices'], f['joints'], vw, jw) @ f['orientations']
+            if initial_shape_betas is not None or initial_kid_factor is not None:
+                reg_ref = np.zeros((B, self.S_all), np.float64)
+                if initial_shape_betas is not None:
+                    nbg = min(np.asarray(initial_shape_betas).shape[1], m.S)
+                    reg_ref[:, :nbg] = np.asarray(initial_shape_betas)[:, :nbg]
+                if self.enable_kid and initial_kid_factor is not None:
+                    reg_ref[:, m.S] = np.asarray(initial_kid_factor).reshape(-1)
+        else:
+            G = self.fit_global_rotations(tv, tj, self.default_mesh[None], m.J_template[None], vw, jw)
         stages['glob_rotmats_iter0'] = G.copy()
         for it in range(num_iter - 1):
-            r = self.fit_shape(G, tv, tj, vw, jw, beta_regularizer, beta_regularizer2, kid_regularizer)
+            r = self.fit_shape(G, tv, tj, vw, jw, beta_regularizer, beta_regularizer2, kid_regularizer,
+                               reg_ref)
             if it == 0:
                 stages['gram_cen0'], stages['rhs_cen0'] = r['gram_cen'], r['rhs_cen']
                 stages['shape_betas0'], stages['trans0'] = r['shape_betas'], r['trans']
             rj = r['joints'] if tj is not None else None
             G = self.fit_global_rotations(tv, tj, r['vertices'], rj, vw, jw) @ G
-        r = self.fit_shape(G, tv, tj, vw, jw, beta_regularizer, beta_regularizer2, kid_regularizer)
+        r = self.fit_shape(G, tv, tj, vw, jw, beta_regularizer, beta_regularizer2, kid_regularizer,
+                           reg_ref)
         if num_iter == 1:
             stages['gram_cen0'], stages['rhs_cen0'] = r['gram_cen'], r['rhs_cen']
             stages['shape_betas0'], stages['trans0'] = r['shape_betas'], r['trans']

@@ -8,7 +8,9 @@ share targets; only outputs are stored here:
   (reference pt/bodyfitter.py:655-838) over cases covering ``num_iter``, joints given / omitted,
   weights, ``scale_fit``, ``kid_factor``, ``initial_pose_rotvecs`` and ``final_adjust_rots``;
 * ``scaletrans.<case>.{scale,trans}`` for the module-level ``fit_scale_and_translation``
-  (pt/bodyfitter.py:1628-1681).
+  (pt/bodyfitter.py:1628-1681);
+* ``warm.<case>.*`` for ``fit`` with ``initial_pose_rotvecs / initial_shape_betas / initial_kid_factor``
+  (:363-382), including BodyFlipper's configuration (pt/bodyflipper.py:71-81).
 
 Usage:  python tests/golden/make_golden_ext.py
 """
@@ -29,7 +31,8 @@ from smplfitter.pt.bodyfitter import fit_scale_and_translation  # noqa: E402
 from smplfitter_amd import synth  # noqa: E402
 
 sys.path.insert(0, osp.join(HERE, '..'))
-from util import KNOWN_SHAPE_CASES, SCALE_TRANS_CASES, known_shape_inputs, scale_trans_inputs  # noqa: E402
+from util import (KNOWN_SHAPE_CASES, SCALE_TRANS_CASES, WARM_CASES, known_shape_inputs,  # noqa: E402
+                  scale_trans_inputs, warm_inputs)
 
 def main():
     torch.set_num_threads(8)
@@ -60,6 +63,17 @@ def main():
                 for k in ('pose_rotvecs', 'trans', 'orientations', 'scale_corr'):
                     if k in r:
                         out[f'knownshape.{case}.{k}'] = r[k].numpy()
+            kfitter = ref.BodyFitter(model, enable_kid=True)
+            for case in WARM_CASES:
+                if kind != 'smpl' and case not in ('a', 'c'):
+                    continue
+                kid_fit, tv, kw = warm_inputs(g, case)
+                kwt = {k: (T(v) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+                r = (kfitter if kid_fit else fitter).fit(
+                    T(tv), requested_keys=['pose_rotvecs', 'shape_betas', 'trans'], **kwt)
+                for k in ('pose_rotvecs', 'shape_betas', 'trans', 'kid_factor', 'orientations'):
+                    if k in r:
+                        out[f'warm.{case}.{k}'] = r[k].numpy()
             if kind == 'smpl':
                 tv, tj, rv, rj, vw, jw = scale_trans_inputs(g)
                 for case, (uj, uw, sc) in SCALE_TRANS_CASES.items():

@@ -174,3 +174,22 @@ def test_known_shape_and_scale_goldens(name, model_root, golden):
             assert np.abs(t - ge[f'scaletrans.{case}.trans']).max() < 1e-5, case
             if sc:
                 assert np.abs(s - ge[f'scaletrans.{case}.scale']).max() < 1e-5, case
+
+
+@pytest.mark.parametrize('name', ['smpl', 'smplx'])
+def test_warm_start_goldens(name, model_root, golden):
+    """fit with initial_pose_rotvecs / initial_shape_betas / initial_kid_factor: the first rotation pass
+    runs against the model posed with the initial values, and the ridge pulls towards the initial shape
+    (pt/bodyfitter.py:363-382, :1072-1081).  Case c is BodyFlipper's call (pt/bodyflipper.py:71-81)."""
+    g, ge = golden(name), golden(f'ext_{name}')
+    kind, md = util.load_md(model_root, name, g)
+    om, of = util.make_oracle(md, kind)
+    kf = O.OracleFitter(om, enable_kid=True)
+    for case in util.WARM_CASES:
+        if f'warm.{case}.trans' not in ge:
+            continue
+        kid_fit, tv, kw = util.warm_inputs(g, case)
+        kw = dict(kw)
+        tj = kw.pop('target_joints')
+        o = (kf if kid_fit else of).fit(tv, tj, **kw)
+        util.check_warm(om, name, case, o, ge, kid_fit)

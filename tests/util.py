@@ -100,3 +100,48 @@ def check_known_shape(om, name, case, o, ge, betas, kw):
     va = om.forward(o['pose_rotvecs'], betas, o['trans'], kid_factor=kid)['vertices']
     vb = om.forward(ref['pose_rotvecs'], betas, ref['trans'], kid_factor=kid)['vertices']
     assert np.linalg.norm(va - vb, axis=-1).max() < 1e-4, case
+
+
+# warm-started fits (initial_pose_rotvecs / initial_shape_betas / initial_kid_factor, reference
+# pt/bodyfitter.py:363-382 and the regulariser references :1072-1081, :1224-1255)
+# case -> (enable_kid, joints, fit kwargs, which initial values are given)
+WARM_CASES = {
+    'a': (False, True, dict(num_iter=2, beta_regularizer=1.0), ('pose', 'betas')),
+    'b': (False, False, dict(num_iter=1, beta_regularizer=1.0), ('pose',)),
+    'c': (True, False, dict(num_iter=2, beta_regularizer=1e-2, beta_regularizer2=1e-2,
+                            final_adjust_rots=True, kid_regularizer=1e9), ('pose', 'betas')),
+    'd': (True, True, dict(num_iter=3, beta_regularizer=2.0, kid_regularizer=0.5), ('pose', 'betas', 'kid')),
+    'e': (False, True, dict(num_iter=1, beta_regularizer=5.0, final_adjust_rots=False), ('betas',)),
+}
+
+
+def warm_inputs(g, case):
+    kid_fit, joints, kw, given = WARM_CASES[case]
+    rs = np.random.RandomState(321)
+    pose0 = (g['pose'] + rs.randn(*g['pose'].shape) * 0.05).astype(np.float32)
+    betas0 = (g['betas'] + rs.randn(*g['betas'].shape) * 0.2).astype(np.float32)
+    kid0 = (g['kid'] + rs.randn(*g['kid'].shape) * 0.1).astype(np.float32)
+    use_kid_target = kid_fit and 'kid' in given
+    tv = g['kid.target_vertices'] if use_kid_target else g['target_vertices']
+    tj = g['kid.target_joints'] if use_kid_target else g['target_joints']
+    kw = dict(kw)
+    kw['target_joints'] = tj if joints else None
+    kw['initial_pose_rotvecs'] = pose0 if 'pose' in given else None
+    kw['initial_shape_betas'] = betas0 if 'betas' in given else None
+    kw['initial_kid_factor'] = kid0 if 'kid' in given else None
+    return kid_fit, tv, kw
+
+
+def check_warm(om, name, case, o, ge, kid_fit):
+    """Assertions of a warm-started fit against the reference's fixture (mesh gate 1e-4 m)."""
+    keys = ('pose_rotvecs', 'shape_betas', 'trans') + (('kid_factor',) if kid_fit else ())
+    ref = {k: ge[f'warm.{case}.{k}'] for k in keys}
+    kw_o = dict(kid_factor=o['kid_factor']) if kid_fit else {}
+    kw_r = dict(kid_factor=ref['kid_factor']) if kid_fit else {}
+    va = om.forward(o['pose_rotvecs'], o['shape_betas'], o['trans'], **kw_o)['vertices']
+    vb = om.forward(ref['pose_rotvecs'], ref['shape_betas'], ref['trans'], **kw_r)['vertices']
+    assert np.linalg.norm(va - vb, axis=-1).max() < 1e-4, case
+    assert np.abs(o['trans'] - ref['trans']).max() < 2e-5, case
+    assert np.abs(o['shape_betas'] - ref['shape_betas']).max() < (3e-4 if name == 'smpl' else 1e-3), case
+    if kid_fit:
+        assert np.abs(o['kid_factor'] - ref['kid_factor']).max() < 1e-3, case
