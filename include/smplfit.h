@@ -133,6 +133,24 @@ int smplfit_forward_f32(const smplfit_handle* h, const float* pose_rotvecs,
                         float* orientations, void* workspace, size_t workspace_bytes,
                         void* hip_stream);
 
+/* BodyFitter.fit with a warm start (pt/bodyfitter.py:363-382): smplfit_fit_f32 plus
+ *   initial_pose_rotvecs (B,3J) or NULL, initial_shape_betas (B,num_initial_betas) or NULL,
+ *   initial_kid_factor (B) or NULL (enable_kid handles only).
+ * When a pose or betas are given, the first rotation pass runs against the model posed with the initial
+ * values (composed with its orientations) instead of the template, and the ridge of every shape solve
+ * pulls towards initial_shape_betas / initial_kid_factor (beta/kid_regularizer_reference, :1072-1081,
+ * :1224-1255).  All three NULL is exactly smplfit_fit_f32.  This is the call BodyFlipper.flip makes
+ * (pt/bodyflipper.py:71-81). */
+int smplfit_fit_warm_f32(const smplfit_handle* h, const float* target_vertices,
+                         const float* target_joints, const float* vertex_weights,
+                         const float* joint_weights, int batch, int num_iter, float beta_regularizer,
+                         float beta_regularizer2, float kid_regularizer, int final_adjust_rots,
+                         const float* initial_pose_rotvecs, const float* initial_shape_betas,
+                         int num_initial_betas, const float* initial_kid_factor, float* pose_rotvecs,
+                         float* shape_betas, float* trans, float* kid_factor, float* orientations,
+                         float* relative_orientations, void* workspace, size_t workspace_bytes,
+                         void* hip_stream);
+
 /* BodyFitter.fit_with_known_shape (pt/bodyfitter.py:655-838): pose and translation (and, with
  * scale_fit, one scale factor per instance) for KNOWN shape parameters.  num_iter rotation passes
  * against the model posed at the current rotations, then fit_scale_and_translation (:1628-1681) and,

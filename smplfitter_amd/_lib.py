@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     'smplfit_create', 'smplfit_destroy', 'smplfit_last_error', 'smplfit_version',
     'smplfit_get_info', 'smplfit_get_table', 'smplfit_workspace_bytes', 'smplfit_fit_f32',
     'smplfit_forward_f32', 'smplfit_part_rotations_f32', 'smplfit_shape_solve_f32',
-    'smplfit_fit_known_shape_f32', 'smplfit_time_kernel_f32',
+    'smplfit_fit_known_shape_f32', 'smplfit_fit_warm_f32', 'smplfit_time_kernel_f32',
 ]  # fmt: skip
 
 _fp = C.POINTER(C.c_float)
@@ -109,6 +109,8 @@ def load():
     lib.smplfit_workspace_bytes.restype = sz
     lib.smplfit_fit_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.smplfit_fit_f32.restype = i32
+    lib.smplfit_fit_warm_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    lib.smplfit_fit_warm_f32.restype = i32
     lib.smplfit_forward_f32.argtypes = [vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, sz, vp]
     lib.smplfit_forward_f32.restype = i32
     lib.smplfit_part_rotations_f32.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, sz, vp]

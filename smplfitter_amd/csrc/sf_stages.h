@@ -305,13 +305,14 @@ SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
 // translation; joints and per-joint skinning translations at the solution.
 //   _fit_shape_gram, bodyfitter.py:1054-1101.
 // gramv: NE+1 doubles (vertex block incl. W), gramj: NE+1 floats (joint block incl. W).
+// reg_ref (S) or null: values the ridge pulls towards (warm-started fit).
 // Outputs: beta (S), trans (3), rjoints (J,3), jb (J,4) = T0 + T' beta (skinning translation).
 // ---------------------------------------------------------------------------------------------
 template <class Ctx>
 SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const double* gramv,
                        const float* gramj, const float* pext, const float* jd, const float* mb,
                        float beta_reg, float beta_reg2, float kid_reg, float* beta_out, float* trans_out,
-                       float* rjoints_out, float* jb_out) {
+                       float* rjoints_out, float* jb_out, const float* reg_ref = nullptr) {
   const int J = tb.J, S = tb.S, S1 = S + 1;
   const int NG = ne_ng(S), NE = ne_size(S);
   double* sum = reinterpret_cast<double*>(scratch);  // NE+1   (scratch is 8-byte aligned)
@@ -346,8 +347,12 @@ SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const doubl
       M[i * S + j] = g;
     }
   }
-  SF_FOR(i, S)
-  x[i] = sum[NG + i] - (SA[i] * Sb[0] + SA[S + i] * Sb[1] + SA[2 * S + i] * Sb[2]) / W;
+  SF_FOR(i, S) {
+    double r = sum[NG + i] - (SA[i] * Sb[0] + SA[S + i] * Sb[1] + SA[2 * S + i] * Sb[2]) / W;
+    if (reg_ref)  // ridge towards reference values: + lambda_i ref_i (:1072-1081, :1224-1255)
+      r += (double)(i >= S - tb.n_kid ? kid_reg : (i < 2 ? beta_reg2 : beta_reg)) * (double)reg_ref[i];
+    x[i] = r;
+  }
   cx.sync();
   // in-place Cholesky M = L L^T (:1083), column by column
   for (int k = 0; k < S; ++k) {

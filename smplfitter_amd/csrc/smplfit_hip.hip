@@ -130,6 +130,7 @@ struct Workspace {
   float* rjreg;    // (B,J,3) regressed reference joints
   float* mbj;      // (B,J,3) per-joint residual moments (pair-Gram form)
   float* scale;    // (B) scale_corr of the known-shape fit
+  float* regref;   // (B,S) ridge reference of the warm-started fit
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -165,6 +166,7 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w) {
   ws.rjreg = (float*)take((size_t)B * J * 3 * 4);
   ws.mbj = (float*)take((size_t)B * J * 3 * 4);
   ws.scale = (float*)take((size_t)B * 4);
+  ws.regref = (float*)take((size_t)B * S * 4);
   if (w) *w = ws;
   return off;
 }
@@ -842,7 +844,8 @@ __global__ __launch_bounds__(64) void k_pair_gram(DevModel m, Workspace ws) {
 // K4: solve.  grid B, block 64.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_shape_solve(DevModel m, Workspace ws, float beta_reg,
-                                                    float beta_reg2, float kid_reg, int pair_form) {
+                                                    float beta_reg2, float kid_reg, int pair_form,
+                                                    int use_ref) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, J = m.J, S = m.S;
   DevCtx cx{(int)threadIdx.x, 64};
@@ -851,7 +854,7 @@ __global__ __launch_bounds__(64) void k_shape_solve(DevModel m, Workspace ws, fl
                   ws.pext + (size_t)b * J * 3 * (S + 1), ws.jd + (size_t)b * J * sf::jd_stride(S),
                   pair_form ? ws.mbj + (size_t)b * J * 3 : nullptr, beta_reg, beta_reg2, kid_reg,
                   ws.beta + (size_t)b * S, ws.trans + (size_t)b * 3, ws.rjoints + (size_t)b * J * 3,
-                  ws.jb + (size_t)b * J * 4);
+                  ws.jb + (size_t)b * J * 4, use_ref ? ws.regref + (size_t)b * S : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1074,8 +1077,10 @@ __global__ void k_fill_shape(Workspace ws, int B, int S, int n_kid, const float*
                              int nb, const float* __restrict__ kid) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  for (int s = 0; s < S - n_kid; ++s) ws.beta[(size_t)b * S + s] = s < nb ? betas[(size_t)b * nb + s] : 0.f;
+  for (int s = 0; s < S - n_kid; ++s)
+    ws.beta[(size_t)b * S + s] = (betas && s < nb) ? betas[(size_t)b * nb + s] : 0.f;
   if (n_kid) ws.beta[(size_t)b * S + S - 1] = kid ? kid[b] : 0.f;
+  for (int s = 0; s < S; ++s) ws.regref[(size_t)b * S + s] = ws.beta[(size_t)b * S + s];
   for (int c = 0; c < 3; ++c) ws.trans[b * 3 + c] = 0.f;
 }
 
@@ -1292,6 +1297,12 @@ struct FitOptions {
   float beta_reg, beta_reg2, kid_reg;
   int final_adjust;
   int rotations_only;  // stop after the first rotation pass, write G to `orient`
+  // warm start (bodyfitter.py:363-382): the first rotation pass runs against the model posed with
+  // these values instead of the template, and the ridge pulls towards init_betas / init_kid
+  const float* init_pose = nullptr;   // (B,3J) or null (rest pose)
+  const float* init_betas = nullptr;  // (B,init_nb) or null
+  int init_nb = 0;
+  const float* init_kid = nullptr;    // (B) or null
 };
 
 int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const float* vw,
@@ -1321,7 +1332,30 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   ja.vertex_sa_closed_form = eff_v ? 0 : 1;
   ja.do_prologue = o.rotations_only ? 0 : 1;
   ja.fit_rotations = 1;
-  if (joints) {
+  ja.Gprev = nullptr;
+  const bool warm = o.init_pose || o.init_betas;
+  const int use_ref = (warm && (o.init_betas || o.init_kid)) ? 1 : 0;
+  if (warm) {
+    hipLaunchKernelGGL(k_fill_shape, dim3((B + 255) / 256), dim3(256), 0, st, ws, B, d.S, d.jt.n_kid,
+                       o.init_betas, std::min(o.init_nb, d.S - d.jt.n_kid), o.init_kid);
+    ForwardArgs fa{};
+    fa.pose = o.init_pose;
+    fa.betas = ws.beta;  // (B,S) incl. the kid column
+    fa.nb = d.S;
+    fa.joints = ws.rjoints;
+    fa.orient = ws.G;
+    hipLaunchKernelGGL(k_forward_joint, dim3(B), dim3(64), joint_lds(d), st, d, fa, ws);
+    launch_gemm(d, ws, B, st);
+#define SF_CALL_LBS(S_, KW_) \
+  launch_lbs<S_, KW_, 1, false>(d, ws, B, vweighted, d.S, ws.beta, ws.trans, nullptr, 0.f, 0.f, st)
+    SF_DISPATCH_SKW(d, SF_CALL_LBS);
+#undef SF_CALL_LBS
+    if (!joints)
+      hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(64), 0, st, d, ws.rverts, ws.rjreg);
+    ja.rj = joints ? ws.rjoints : ws.rjreg;
+    ja.rj_shared = 0;
+    ja.Gprev = ws.G;  // compose with the initial orientations
+  } else if (joints) {
     ja.rj = d.j_template;
     ja.rj_shared = 1;
   } else {  // template joints regressed from the default mesh: same regressor on a (1,3,Vp) source
@@ -1329,7 +1363,6 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     ja.rj = ws.rjreg;
     ja.rj_shared = 1;
   }
-  ja.Gprev = nullptr;
   hipLaunchKernelGGL(k_joint_stage, dim3(B), dim3(64), joint_lds(d), st, d, ja, ws);
   if (o.rotations_only) {
     hipLaunchKernelGGL(k_copy, dim3(256), dim3(256), 0, st, ws.G, orient, (size_t)B * d.J * 9);
@@ -1343,7 +1376,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     // K4 stays its own launch: fused into the prologue of the LBS kernel (template flag SOLVE) its
     // ~40 serial barriers stall all four waves of the workgroup and the kernel ran 230 us longer
     hipLaunchKernelGGL(k_shape_solve, dim3(B), dim3(64), solve_lds(d), st, d, ws, o.beta_reg,
-                       o.beta_reg2, o.kid_reg, (!eff_v && use_pair_form()) ? 1 : 0);
+                       o.beta_reg2, o.kid_reg, (!eff_v && use_pair_form()) ? 1 : 0, use_ref);
     const bool last = it + 1 == o.num_iter;
     if (last && !o.final_adjust) break;  // nothing consumes the re-evaluated mesh
     if (joints) {
@@ -1701,11 +1734,32 @@ int smplfit_fit_f32(const smplfit_handle* h, const float* target_vertices,
                     float* pose_rotvecs, float* shape_betas, float* trans, float* kid_factor,
                     float* orientations, float* relative_orientations, void* workspace,
                     size_t workspace_bytes, void* hip_stream) {
+  return smplfit_fit_warm_f32(h, target_vertices, target_joints, vertex_weights, joint_weights, batch,
+                              num_iter, beta_regularizer, beta_regularizer2, kid_regularizer,
+                              final_adjust_rots, nullptr, nullptr, 0, nullptr, pose_rotvecs, shape_betas,
+                              trans, kid_factor, orientations, relative_orientations, workspace,
+                              workspace_bytes, hip_stream);
+}
+
+int smplfit_fit_warm_f32(const smplfit_handle* h, const float* target_vertices,
+                         const float* target_joints, const float* vertex_weights,
+                         const float* joint_weights, int batch, int num_iter, float beta_regularizer,
+                         float beta_regularizer2, float kid_regularizer, int final_adjust_rots,
+                         const float* initial_pose_rotvecs, const float* initial_shape_betas,
+                         int num_initial_betas, const float* initial_kid_factor, float* pose_rotvecs,
+                         float* shape_betas, float* trans, float* kid_factor, float* orientations,
+                         float* relative_orientations, void* workspace, size_t workspace_bytes,
+                         void* hip_stream) {
   int rc = check_common(h, batch, workspace, workspace_bytes);
   if (rc) return rc;
   if (!target_vertices || !pose_rotvecs || !shape_betas || !trans)
     return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_f32: null input/output pointer");
   if (num_iter < 1) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_f32: num_iter must be >= 1");
+  if (initial_kid_factor && !h->t.n_kid)
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_warm_f32: initial_kid_factor given to a handle without kid");
+  if (initial_shape_betas && num_initial_betas < 0)
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_warm_f32: negative num_initial_betas");
+  const int inb = initial_shape_betas ? num_initial_betas : 0;
   FitOptions o{num_iter, beta_regularizer, beta_regularizer2, kid_regularizer,
                final_adjust_rots ? 1 : 0, 0};
   hipStream_t st = (hipStream_t)hip_stream;
@@ -1715,10 +1769,15 @@ int smplfit_fit_f32(const smplfit_handle* h, const float* target_vertices,
   auto run_chunk = [&](int b0, int nb, char* wsbase, hipStream_t cs) -> int {
     Workspace ws;
     carve(h->t, nb, wsbase, &ws);
+    FitOptions oc = o;
+    oc.init_pose = initial_pose_rotvecs ? initial_pose_rotvecs + (size_t)b0 * J * 3 : nullptr;
+    oc.init_betas = initial_shape_betas ? initial_shape_betas + (size_t)b0 * inb : nullptr;
+    oc.init_nb = inb;
+    oc.init_kid = initial_kid_factor ? initial_kid_factor + b0 : nullptr;
     return run_fit(h, target_vertices + (size_t)b0 * V * 3,
                    target_joints ? target_joints + (size_t)b0 * J * 3 : nullptr,
                    vertex_weights ? vertex_weights + (size_t)b0 * V : nullptr,
-                   joint_weights ? joint_weights + (size_t)b0 * J : nullptr, nb, o,
+                   joint_weights ? joint_weights + (size_t)b0 * J : nullptr, nb, oc,
                    pose_rotvecs + (size_t)b0 * J * 3, shape_betas + (size_t)b0 * Sb,
                    trans + (size_t)b0 * 3, kid_factor ? kid_factor + b0 : nullptr,
                    orientations ? orientations + (size_t)b0 * J * 9 : nullptr,
@@ -1867,7 +1926,7 @@ int smplfit_shape_solve_f32(const smplfit_handle* h, const float* glob_rotmats,
   SF_DISPATCH_SKW(d, SF_CALL_ACCUM);
 #undef SF_CALL_ACCUM
   hipLaunchKernelGGL(k_shape_solve, dim3(batch), dim3(64), solve_lds(d), st, d, ws, beta_regularizer,
-                     beta_regularizer2, kid_regularizer, (!eff_v && use_pair_form()) ? 1 : 0);
+                     beta_regularizer2, kid_regularizer, (!eff_v && use_pair_form()) ? 1 : 0, 0);
   hipLaunchKernelGGL(k_emit_solution, dim3((batch + 255) / 256), dim3(256), 0, st, ws, batch, d.S,
                      d.jt.n_kid, add_mean, shape_betas, trans, kid_factor);
   if (joints_out)
@@ -1906,7 +1965,7 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
       }
       case SMPLFIT_KERNEL_SHAPE_SOLVE:
         hipLaunchKernelGGL(k_shape_solve, dim3(batch), dim3(64), solve_lds(d), st, d, ws, 1.0f, 0.0f, 1.0f,
-                           use_pair_form() ? 1 : 0);
+                           use_pair_form() ? 1 : 0, 0);
         return 0;
       case SMPLFIT_KERNEL_LBS_PARTSUM: {
 #define SF_CALL_LBS(S_, KW_) \

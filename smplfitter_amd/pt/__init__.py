@@ -15,8 +15,10 @@ import torch
 from .bodymodel import BodyModel
 from .bodyfitter import BodyFitter
 from .bodyconverter import BodyConverter
+from .bodyflipper import BodyFlipper
 
-__all__ = ['BodyModel', 'BodyFitter', 'BodyConverter', 'get_cached_body_model', 'get_cached_fit_fn']
+__all__ = ['BodyModel', 'BodyFitter', 'BodyConverter', 'BodyFlipper', 'get_cached_body_model',
+           'get_cached_fit_fn']
 
 
 @functools.lru_cache()

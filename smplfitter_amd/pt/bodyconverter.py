@@ -61,13 +61,17 @@ class BodyConverter(nn.Module):
         num_iter: int = 1,
     ) -> dict[str, torch.Tensor]:
         """Same arguments / results as the reference's ``convert`` (pt/bodyconverter.py:49-126)."""
-        inp_vertices = self.body_model_in(pose_rotvecs, shape_betas, trans, kid_factor=kid_factor)['vertices']
+        # as in the reference (:86), the input mesh is evaluated WITHOUT kid_factor; it only selects the
+        # kid ridge weight and whether kid_factor is returned
+        inp_vertices = self.body_model_in(pose_rotvecs, shape_betas, trans)['vertices']
         verts = self.convert_vertices(inp_vertices)
-        if known_output_shape_betas is not None:
-            raise NotImplementedError(
-                'known_output_shape_betas needs fit_with_known_shape (pt/bodyfitter.py:656-838), '
-                'which the HIP kernels do not implement yet')
         kid_reg = 1e9 if kid_factor is None else 0.0
+        if known_output_shape_betas is not None:  # (:89-98)
+            fit = self.fitter.fit_with_known_shape(
+                shape_betas=known_output_shape_betas, kid_factor=known_output_kid_factor,
+                target_vertices=verts, num_iter=num_iter, final_adjust_rots=False,
+                requested_keys=['pose_rotvecs'])
+            return dict(pose_rotvecs=fit['pose_rotvecs'], trans=fit['trans'])
         if known_output_pose_rotvecs is not None:
             fit = self.fitter.fit_with_known_pose(
                 pose_rotvecs=known_output_pose_rotvecs, target_vertices=verts, beta_regularizer=0.0,

@@ -33,8 +33,7 @@ class BodyFitter(nn.Module):
         self.enable_kid = enable_kid
         self.is_smpl_family = body_model.model_name.startswith('smpl')
 
-    def _check_options(self, share_beta, scale_target, scale_fit, initial_pose_rotvecs,
-                       initial_shape_betas, initial_kid_factor):
+    def _check_options(self, share_beta, scale_target, scale_fit, beta_ref=None, kid_ref=None):
         if scale_target and scale_fit:  # same check, same message as pt/bodyfitter.py:858-859
             raise ValueError('Only one of estim_scale_target and estim_scale_fit can be True')
         unsupported = []
@@ -42,8 +41,8 @@ class BodyFitter(nn.Module):
             unsupported.append('share_beta')
         if scale_target or scale_fit:
             unsupported.append('scale_target/scale_fit')
-        if initial_pose_rotvecs is not None or initial_shape_betas is not None or initial_kid_factor is not None:
-            unsupported.append('initial_* warm start')
+        if beta_ref is not None or kid_ref is not None:
+            unsupported.append('beta/kid_regularizer_reference')
         if unsupported:
             raise NotImplementedError(
                 'not implemented by the HIP fit kernels (reference falls back to _fit_shape_general, '
@@ -73,11 +72,14 @@ class BodyFitter(nn.Module):
     ) -> dict[str, torch.Tensor]:
         """Same arguments and returned keys as the reference's ``fit`` (pt/bodyfitter.py:283-549):
         ``shape_betas, trans, orientations, relative_orientations`` and ``pose_rotvecs`` when
-        requested (default)."""
+        requested (default).  ``initial_pose_rotvecs / initial_shape_betas / initial_kid_factor``
+        warm-start the fit (``smplfit_fit_warm_f32``; reference :363-382)."""
         if requested_keys is None:
             requested_keys = ['pose_rotvecs']
-        self._check_options(share_beta, scale_target, scale_fit, initial_pose_rotvecs,
-                            initial_shape_betas, initial_kid_factor)
+        self._check_options(share_beta, scale_target, scale_fit)
+        if initial_kid_factor is not None and not self.enable_kid:
+            raise NotImplementedError(
+                'initial_kid_factor needs BodyFitter(enable_kid=True) on the HIP path')
         bm = self.body_model
         device = bm.v_template.device
         for t in (target_vertices, target_joints, vertex_weights, joint_weights):
@@ -95,6 +97,12 @@ class BodyFitter(nn.Module):
             raise ValueError(f'vertex_weights must have shape ({B}, {V})')
         if jw is not None and tuple(jw.shape) != (B, J):
             raise ValueError(f'joint_weights must have shape ({B}, {J})')
+        init_pose = None if initial_pose_rotvecs is None else prep(initial_pose_rotvecs.reshape(B, J * 3))
+        init_betas = None if initial_shape_betas is None else prep(initial_shape_betas)[:, :S].contiguous()
+        init_kid = None
+        if initial_kid_factor is not None:
+            init_kid = torch.as_tensor(initial_kid_factor, dtype=torch.float32, device=device).reshape(-1)
+            init_kid = init_kid.expand(B).contiguous() if init_kid.numel() == 1 else init_kid.contiguous()
         pose = torch.empty((B, 3 * J), dtype=torch.float32, device=device)
         betas = torch.empty((B, S), dtype=torch.float32, device=device)
         trans = torch.empty((B, 3), dtype=torch.float32, device=device)
@@ -108,11 +116,13 @@ class BodyFitter(nn.Module):
             ws = _workspace if _workspace is not None else bm._workspace(h, B, device)
             with torch.cuda.device(device):
                 stream = torch.cuda.current_stream(device).cuda_stream
-                _lib.check(_lib.load().smplfit_fit_f32(
+                _lib.check(_lib.load().smplfit_fit_warm_f32(
                     h.ptr, _ptr(tv), _ptr(tj), _ptr(vw), _ptr(jw), B, int(num_iter),
                     float(beta_regularizer), float(beta_regularizer2), kid_reg,
-                    int(bool(final_adjust_rots)), _ptr(pose), _ptr(betas), _ptr(trans), _ptr(kid),
-                    _ptr(orient), _ptr(rel), _ptr(ws), ws.numel(), C.c_void_p(stream)))
+                    int(bool(final_adjust_rots)), _ptr(init_pose), _ptr(init_betas),
+                    0 if init_betas is None else init_betas.shape[1], _ptr(init_kid), _ptr(pose),
+                    _ptr(betas), _ptr(trans), _ptr(kid), _ptr(orient), _ptr(rel), _ptr(ws), ws.numel(),
+                    C.c_void_p(stream)))
         # relative_orientations = parent^T @ global of the FINAL rotations (pt/bodyfitter.py:523-533);
         # returned always (the reference returns the pre-refinement ones when neither
         # 'relative_orientations' nor 'pose_rotvecs' is requested)
@@ -144,7 +154,7 @@ class BodyFitter(nn.Module):
         """Shape and translation for a known pose (reference pt/bodyfitter.py:552-653): global
         rotations by forward kinematics of ``pose_rotvecs`` (the HIP forward kernel), then one shape
         solve with the target mean added back."""
-        self._check_options(share_beta, scale_target, scale_fit, None, beta_regularizer_reference,
+        self._check_options(share_beta, scale_target, scale_fit, beta_regularizer_reference,
                             kid_regularizer_reference)
         bm = self.body_model
         B = target_vertices.shape[0]

@@ -293,3 +293,48 @@ def subset_indices(num_vertices, part_assignment, size=1024, min_per_part=8, see
     rest = np.array([i for i in range(num_vertices) if i not in chosen])
     extra = rs.choice(rest, size=size - len(chosen), replace=False)
     return np.sort(np.concatenate([np.array(sorted(chosen)), extra])).astype(np.int64)
+
+
+def _nearest3(src_pts, query_pts):
+    """For each query point: the 3 nearest source points and inverse-distance weights (sum 1)."""
+    from scipy.spatial import cKDTree
+
+    d, idx = cKDTree(src_pts).query(query_pts, k=3)
+    w = 1.0 / (d + 1e-4)
+    w /= w.sum(1, keepdims=True)
+    return idx.astype(np.int64), w.astype(np.float32)
+
+
+def write_transfer_files(data_root, seed=0):
+    """Synthetic stand-ins, in the official file layouts, for the topology-transfer and mirror files
+    ``BodyConverter`` / ``BodyFlipper`` read under ``$DATA_ROOT/body_models`` (reference
+    common.py:425-429, pt/bodyflipper.py:136-169):
+
+    * ``smpl2smplx_deftrafo_setup.pkl`` / ``smplx2smpl_deftrafo_setup.pkl``: ``{'mtx': (V_out, 2 V_in)}``
+      scipy CSR whose first V_in columns are a barycentric transfer (3 nearest template vertices);
+    * ``smplx/smplx_flip_correspondences.npz``: ``closest_faces (V,3)``, ``bc (V,3)`` — for every SMPL-X
+      vertex the 3 template vertices nearest to its mirror image and their weights.
+    Returns ``data_root``."""
+    import scipy.sparse as sp
+
+    smpl = make_model_arrays('smpl', seed)['v_template'].astype(np.float64)
+    smplx = make_model_arrays('smplx', seed)['v_template'].astype(np.float64)
+    d = osp.join(data_root, 'body_models')
+    os.makedirs(osp.join(d, 'smplx'), exist_ok=True)
+
+    def dump(name, src, dst):
+        idx, w = _nearest3(src, dst)
+        rows = np.repeat(np.arange(len(dst)), 3)
+        m = sp.csr_matrix((w.reshape(-1), (rows, idx.reshape(-1))), shape=(len(dst), len(src)))
+        tmp = osp.join(d, name + f'.tmp{os.getpid()}')
+        with open(tmp, 'wb') as f:
+            pickle.dump(dict(mtx=sp.hstack([m, m]).tocsr()), f, protocol=2)
+        os.replace(tmp, osp.join(d, name))
+
+    dump('smpl2smplx_deftrafo_setup.pkl', smpl, smplx)
+    dump('smplx2smpl_deftrafo_setup.pkl', smplx, smpl)
+    idx, w = _nearest3(smplx, smplx * np.array([-1.0, 1.0, 1.0]))
+    tmp = osp.join(d, 'smplx', f'flip.tmp{os.getpid()}.npz')
+    np.savez(tmp, closest_faces=idx, bc=w)
+    os.replace(tmp, osp.join(d, 'smplx', 'smplx_flip_correspondences.npz'))
+    return data_root

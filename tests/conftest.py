@@ -36,3 +36,11 @@ def golden():
         return dict(np.load(osp.join(gdir, f'golden_{name}.npz'), allow_pickle=False))
 
     return load
+
+
+@pytest.fixture(scope='session')
+def data_root():
+    """Synthetic topology-transfer / mirror files in the official layout ($DATA_ROOT/body_models)."""
+    from smplfitter_amd import synth
+
+    return synth.write_transfer_files(os.getenv('SMPLFIT_SYNTH_DATA', '/tmp/smplfit_synth_data_seed0'))

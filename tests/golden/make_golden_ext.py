@@ -10,7 +10,9 @@ share targets; only outputs are stored here:
 * ``scaletrans.<case>.{scale,trans}`` for the module-level ``fit_scale_and_translation``
   (pt/bodyfitter.py:1628-1681);
 * ``warm.<case>.*`` for ``fit`` with ``initial_pose_rotvecs / initial_shape_betas / initial_kid_factor``
-  (:363-382), including BodyFlipper's configuration (pt/bodyflipper.py:71-81).
+  (:363-382), including BodyFlipper's configuration (pt/bodyflipper.py:71-81);
+* ``flip.*`` for ``BodyFlipper`` (mirror joint permutation, ``flip_vertices`` sampled every 50th vertex,
+  ``naive_flip_rotvecs``, ``flip`` results) on the synthetic mirror / transfer files.
 
 Usage:  python tests/golden/make_golden_ext.py
 """
@@ -74,6 +76,22 @@ def main():
                 for k in ('pose_rotvecs', 'shape_betas', 'trans', 'kid_factor', 'orientations'):
                     if k in r:
                         out[f'warm.{case}.{k}'] = r[k].numpy()
+            # BodyFlipper (pt/bodyflipper.py) on the synthetic mirror / transfer files of
+            # synth.write_transfer_files
+            os.environ['DATA_ROOT'] = synth.write_transfer_files(
+                os.getenv('SMPLFIT_SYNTH_DATA', '/tmp/smplfit_synth_data_seed0'))
+            flipper = ref.BodyFlipper(model)
+            out['flip.mirror_inds_joints'] = flipper.mirror_inds_joints.numpy()
+            out['flip.vertices_sub'] = flipper.flip_vertices(T(g['target_vertices'])).numpy()[:, ::50]
+            out['flip.naive_rotvecs'] = flipper.naive_flip_rotvecs(T(g['pose'])).numpy()
+            for tag, kidf, ni in (('a', None, 1), ('b', None, 3), ('c', g.get('kid'), 2)):
+                if kidf is None and tag == 'c':
+                    continue
+                r = flipper.flip(T(g['pose']), T(g['betas']), T(g['trans']),
+                                 kid_factor=None if kidf is None else T(kidf), num_iter=ni)
+                for k in ('pose_rotvecs', 'shape_betas', 'trans', 'kid_factor'):
+                    if r.get(k) is not None:
+                        out[f'flip.{tag}.{k}'] = r[k].numpy()
             if kind == 'smpl':
                 tv, tj, rv, rj, vw, jw = scale_trans_inputs(g)
                 for case, (uj, uw, sc) in SCALE_TRANS_CASES.items():

@@ -45,7 +45,7 @@ struct Emu {
   sf::JointTabs jt;
   int B;
   std::vector<float> tvs, vws, vposed, rp, mean, tjc, psum, G, jd, pext, gramj, beta, trans, jb,
-      rjoints, rverts, tjreg, rjreg, scratch;
+      rjoints, rverts, tjreg, rjreg, scratch, regref;  // regref: (B,S) ridge reference, empty = none
   std::vector<double> gramv;
   sf::JointScratch sh;
   std::vector<float> solve_scratch;
@@ -232,7 +232,8 @@ struct Emu {
                       pext.data() + (size_t)b * J * 3 * (S + 1), jd_b(b),
                       use_pair_gram ? mbj.data() + (size_t)b * J * 3 : nullptr, reg, reg2, kid_reg,
                       beta.data() + (size_t)b * S, trans.data() + (size_t)b * 3,
-                      rjoints.data() + (size_t)b * J * 3, jb.data() + (size_t)b * J * 4);
+                      rjoints.data() + (size_t)b * J * 3, jb.data() + (size_t)b * J * 4,
+                      regref.empty() ? nullptr : regref.data() + (size_t)b * S);
   }
 
   void vertex(int b, int i, const float* be, int nb, const float* tr, float* v) {
@@ -268,10 +269,19 @@ struct Emu {
 
 thread_local std::string g_err;
 
+struct Warm {  // warm start of fit (mirrors FitOptions::init_* in smplfit_hip.hip)
+  const float* pose = nullptr;
+  const float* betas = nullptr;
+  int nb = 0;
+  const float* kid = nullptr;
+};
+thread_local Warm g_warm;  // set by hostemu_fit_warm around hostemu_fit
+
 template <int S, int KW>
 int fit_impl(const sf::HostTables& t, const float* tv, const float* tj, const float* vw,
              const float* jw, int B, int num_iter, float reg, float reg2, float kid_reg, int final_adjust,
              float* pose, float* betas, float* trans, float* kid, float* orient, float* G0_out) {
+  const Warm w = g_warm;
   Emu<S, KW> e(t, B);
   const bool joints = tj != nullptr;
   const bool eff_v = joints ? (vw && jw) : (vw != nullptr);
@@ -288,7 +298,34 @@ int fit_impl(const sf::HostTables& t, const float* tv, const float* tj, const fl
   } else {
     rj0 = jtemplate;
   }
-  e.k1(tj_rot, rj0.data(), true, nullptr, jw, true, true, joints, eff_j, !eff_v);
+  const bool warm = w.pose || w.betas;
+  if (warm) {
+    const int nbe = std::min(w.nb, S - t.n_kid);
+    for (int b = 0; b < B; ++b) {
+      for (int s = 0; s < S - t.n_kid; ++s)
+        e.beta[(size_t)b * S + s] = (w.betas && s < nbe) ? w.betas[(size_t)b * w.nb + s] : 0.f;
+      if (t.n_kid) e.beta[(size_t)b * S + S - 1] = w.kid ? w.kid[b] : 0.f;
+      for (int c = 0; c < 3; ++c) e.trans[(size_t)b * 3 + c] = 0.f;
+    }
+    if (w.betas || w.kid) e.regref = e.beta;
+    HostCtx cx;
+    for (int b = 0; b < B; ++b) {
+      sf::forward_joint_stage(cx, e.jt, e.sh, w.pose ? w.pose + (size_t)b * t.J * 3 : nullptr, nullptr,
+                              e.beta.data() + (size_t)b * S, S, nullptr, nullptr,
+                              e.rp.data() + (size_t)b * t.Kp, e.jd_b(b),
+                              e.rjoints.data() + (size_t)b * t.J * 3, e.G.data() + (size_t)b * t.J * 9);
+      for (int k = 0; k < t.J * 3; ++k)
+        e.jb[(size_t)b * t.J * 4 + (k / 3) * 4 + k % 3] = e.jd_b(b)[(k / 3) * sf::jd_stride(S) + 9 + k % 3];
+    }
+    e.gemm();
+    e.k5(vw != nullptr, true);
+    if (!joints) e.regress(e.rverts.data(), false, e.rjreg.data(), B);
+    std::vector<float> Gprev = e.G;
+    e.k1(tj_rot, joints ? e.rjoints.data() : e.rjreg.data(), false, Gprev.data(), jw, true, true, joints,
+         eff_j, !eff_v);
+  } else {
+    e.k1(tj_rot, rj0.data(), true, nullptr, jw, true, true, joints, eff_j, !eff_v);
+  }
   if (G0_out) std::memcpy(G0_out, e.G.data(), sizeof(float) * (size_t)B * t.J * 9);
   for (int it = 0; it < num_iter; ++it) {
     e.gemm();
@@ -444,6 +481,21 @@ int hostemu_fit(const smplfit_model_desc* d, const float* tv, const float* tj, c
     return fit_impl<11, 4>(t, tv, tj, vw, jw, B, num_iter, reg, reg2, kid_reg, final_adjust, pose, betas, trans, kid, orient, G0_out);
   g_err = "hostemu: unsupported (S, KW)";
   return -2;
+}
+
+int hostemu_fit_warm(const smplfit_model_desc* d, const float* tv, const float* tj, const float* vw,
+                     const float* jw, int B, int num_iter, float reg, float reg2, float kid_reg,
+                     int final_adjust, const float* init_pose, const float* init_betas, int init_nb,
+                     const float* init_kid, float* pose, float* betas, float* trans, float* kid,
+                     float* orient) {
+  g_warm.pose = init_pose;
+  g_warm.betas = init_betas;
+  g_warm.nb = init_betas ? init_nb : 0;
+  g_warm.kid = init_kid;
+  const int rc = hostemu_fit(d, tv, tj, vw, jw, B, num_iter, reg, reg2, kid_reg, final_adjust, pose, betas,
+                             trans, kid, orient, nullptr);
+  g_warm = Warm();
+  return rc;
 }
 
 int hostemu_fit_known_shape(const smplfit_model_desc* d, const float* betas, int nb, const float* kid,

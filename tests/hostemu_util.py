@@ -38,6 +38,8 @@ def load():
     lib.hostemu_fit.restype = i32
     lib.hostemu_forward.argtypes = [C.POINTER(_lib.ModelDesc), vp, vp, vp, i32, vp, vp, i32, vp, vp, vp]
     lib.hostemu_forward.restype = i32
+    lib.hostemu_fit_warm.argtypes = [C.POINTER(_lib.ModelDesc), vp, vp, vp, vp, i32, i32, f32, f32, f32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp]
+    lib.hostemu_fit_warm.restype = i32
     lib.hostemu_fit_known_shape.argtypes = [C.POINTER(_lib.ModelDesc), vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.hostemu_fit_known_shape.restype = i32
     lib.hostemu_last_error.restype = C.c_char_p
@@ -127,4 +129,33 @@ def fit_known_shape(md, kind, betas, tv, target_joints=None, vertex_weights=None
     out = dict(pose_rotvecs=pose, trans=trans, orientations=orient)
     if scale_fit:
         out['scale_corr'] = scale
+    return out
+
+
+def fit_warm(md, kind, tv, target_joints=None, vertex_weights=None, joint_weights=None, num_iter=1,
+             beta_regularizer=1.0, beta_regularizer2=0.0, final_adjust_rots=True, enable_kid=False,
+             kid_regularizer=None, initial_pose_rotvecs=None, initial_shape_betas=None,
+             initial_kid_factor=None):
+    lib = load()
+    desc, keep = desc_from_md(md, kind, enable_kid)
+    if kid_regularizer is None:
+        kid_regularizer = beta_regularizer
+    f = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)  # noqa: E731
+    tv, tj, vw, jw = f(tv), f(target_joints), f(vertex_weights), f(joint_weights)
+    ip, ib, ik = f(initial_pose_rotvecs), f(initial_shape_betas), f(initial_kid_factor)
+    B, J, S = tv.shape[0], md.num_joints, md.shapedirs.shape[2]
+    pose = np.zeros((B, 3 * J), np.float32)
+    betas = np.zeros((B, S), np.float32)
+    trans = np.zeros((B, 3), np.float32)
+    orient = np.zeros((B, J, 3, 3), np.float32)
+    kid = np.zeros((B,), np.float32)
+    rc = lib.hostemu_fit_warm(C.byref(desc), _p(tv), _p(tj), _p(vw), _p(jw), B, num_iter, beta_regularizer,
+                              beta_regularizer2, kid_regularizer, int(final_adjust_rots), _p(ip), _p(ib),
+                              0 if ib is None else ib.shape[1], _p(ik), _p(pose), _p(betas), _p(trans),
+                              _p(kid), _p(orient))
+    if rc != 0:
+        raise RuntimeError(lib.hostemu_last_error().decode())
+    out = dict(pose_rotvecs=pose, shape_betas=betas, trans=trans, orientations=orient)
+    if enable_kid:
+        out['kid_factor'] = kid
     return out

@@ -357,3 +357,58 @@ def test_known_shape_vs_oracle_and_roundtrip(model_root, golden, dev):
             assert np.abs(r['scale_corr'] - o['scale_corr']).max() < 1e-5
         else:  # 3 mm of noise: the fitted mesh is within a few mm of the clean one
             assert np.linalg.norm(va - fw['vertices'], axis=-1).mean() < 5e-3
+
+
+@pytest.mark.parametrize('name', ['smpl', 'smplx'])
+def test_warm_start_goldens(name, model_root, golden, dev):
+    """fit(initial_pose_rotvecs=, initial_shape_betas=, initial_kid_factor=) (smplfit_fit_warm_f32)
+    against the reference's fixture; case c is BodyFlipper's configuration."""
+    from smplfitter_amd.pt import BodyFitter
+
+    g, ge = golden(name), golden(f'ext_{name}')
+    kind, md = util.load_md(model_root, name, g)
+    om, _ = util.make_oracle(md, kind, np.float64)
+    m, f = get_model(model_root, name, g, dev)
+    kf = BodyFitter(m, enable_kid=True)
+    for case in util.WARM_CASES:
+        if f'warm.{case}.trans' not in ge:
+            continue
+        kid_fit, tv, kw = util.warm_inputs(g, case)
+        kwt = {k: (t(v, dev) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+        o = to_np((kf if kid_fit else f).fit(t(tv, dev), requested_keys=['pose_rotvecs'], **kwt))
+        util.check_warm(om, name, case, o, ge, kid_fit)
+    # all initial values None is the plain fit
+    a = to_np(f.fit(t(g['target_vertices'], dev), t(g['target_joints'], dev), num_iter=2))
+    b = to_np(f.fit(t(g['target_vertices'], dev), t(g['target_joints'], dev), num_iter=2,
+                    initial_pose_rotvecs=None, initial_shape_betas=None))
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+
+
+@pytest.mark.parametrize('name', ['smpl', 'smplx'])
+def test_body_flipper(name, model_root, data_root, golden, dev, monkeypatch):
+    """BodyFlipper.flip end to end (forward -> mirror matrix -> warm-started kid fit) against the
+    reference run on the same synthetic mirror / transfer files."""
+    from smplfitter_amd.pt import BodyFlipper
+
+    monkeypatch.setenv('DATA_ROOT', data_root)
+    g, ge = golden(name), golden(f'ext_{name}')
+    kind, md = util.load_md(model_root, name, g)
+    om, _ = util.make_oracle(md, kind, np.float64)
+    m, _ = get_model(model_root, name, g, dev)
+    fl = BodyFlipper(m)
+    assert (fl.mirror_inds_joints.cpu().numpy() == ge['flip.mirror_inds_joints']).all()
+    fv = fl.flip_vertices(t(g['target_vertices'], dev)).cpu().numpy()
+    assert np.abs(fv[:, ::50] - ge['flip.vertices_sub']).max() < 2e-6
+    nr = fl.naive_flip_rotvecs(t(g['pose'], dev)).cpu().numpy()
+    assert np.abs(nr - ge['flip.naive_rotvecs']).max() == 0
+    for tag, kid, ni in (('a', None, 1), ('b', None, 3), ('c', g['kid'], 2)):
+        r = fl.flip(t(g['pose'], dev), t(g['betas'], dev), t(g['trans'], dev),
+                    kid_factor=None if kid is None else t(kid, dev), num_iter=ni)
+        assert r['kid_factor'] is not None  # the kid fitter always reports it (pinned to ~0 without input)
+        o = {k: v.cpu().numpy() for k, v in r.items() if v is not None}
+        ref = {k: ge[f'flip.{tag}.{k}'] for k in ('pose_rotvecs', 'shape_betas', 'trans', 'kid_factor')}
+        va = om.forward(o['pose_rotvecs'], o['shape_betas'], o['trans'], kid_factor=o['kid_factor'])['vertices']
+        vb = om.forward(ref['pose_rotvecs'], ref['shape_betas'], ref['trans'], kid_factor=ref['kid_factor'])['vertices']
+        assert np.linalg.norm(va - vb, axis=-1).max() < 1e-4, tag
+        assert np.abs(o['trans'] - ref['trans']).max() < 2e-5, tag
+        assert np.abs(o['shape_betas'] - ref['shape_betas']).max() < 1e-3, tag

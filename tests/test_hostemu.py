@@ -119,3 +119,17 @@ def test_known_shape_goldens(name, model_root, golden):
         betas, tv, kw = util.known_shape_inputs(g, case)
         o = H.fit_known_shape(md, kind, betas, tv, **kw)
         util.check_known_shape(om, name, case, o, ge, betas, kw)
+
+
+@pytest.mark.parametrize('name', ['smpl', 'smplx'])
+def test_warm_start_goldens(name, model_root, golden):
+    """Warm-started fit (initial pose / betas / kid + ridge references) through the shared stage code."""
+    g, ge = golden(name), golden(f'ext_{name}')
+    kind, md = util.load_md(model_root, name, g)
+    om, _ = util.make_oracle(md, kind, np.float64)
+    for case in util.WARM_CASES:
+        if f'warm.{case}.trans' not in ge:
+            continue
+        kid_fit, tv, kw = util.warm_inputs(g, case)
+        o = H.fit_warm(md, kind, tv, enable_kid=kid_fit, **kw)
+        util.check_warm(om, name, case, o, ge, kid_fit)
