@@ -155,7 +155,16 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
     int p = t.part_assignment[v];
     return (t.used_part[p] ? 0 : kMaxJoints) + p;
   };
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key(a) < key(b); });
+  // within a part: by the set of skinning joints, so that runs with few distinct joints are long
+  // (vertex groups of the batch-major kernels)
+  std::vector<uint64_t> jmask(V, 0);
+  for (int v = 0; v < V; ++v)
+    for (int j = 0; j < J; ++j)
+      if (d.weights[(size_t)v * J + j] != 0.f) jmask[v] |= (uint64_t)1 << j;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    const int ka = key(a), kb = key(b);
+    return ka != kb ? ka < kb : jmask[a] < jmask[b];
+  });
   const int Vp = t.Vp;
   t.perm.assign(Vp, -1);
   t.slot_part.assign(Vp, -1);
@@ -237,6 +246,55 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
     };
     t.cpackA.assign((size_t)Vp * cs, 0.f);
     for (int i = 0; i < Vp; ++i) pack(t.cpackA.data() + (size_t)i * cs, i);
+    // vertex groups: greedy runs inside a part with at most kGroupJoints distinct joints
+    t.groups.clear();
+    const int bs = t.brec_stride(), bw = t.brec_w(), bd = t.brec_d();
+    t.brec.assign((size_t)Vp * bs, 0.f);
+    for (int i = 0; i < V;) {
+      const int p = t.slot_part[i];
+      VertexGroup g{};
+      g.start = i;
+      g.part = p;
+      g.used = t.used_part[p] ? 1 : 0;
+      uint64_t set = 0;
+      int e = i;
+      while (e < V && t.slot_part[e] == p) {
+        const uint64_t u = set | jmask[t.perm[e]];
+        if (__builtin_popcountll(u) > kGroupJoints) break;
+        set = u;
+        ++e;
+      }
+      if (e == i) return "smplfit_create: a vertex has more skinning joints than a vertex group holds";
+      g.count = e - i;
+      int local[kMaxJoints];
+      for (int j = 0; j < J; ++j)
+        if ((set >> j) & 1) {
+          local[j] = g.nq;
+          g.joints[g.nq++] = j;
+        }
+      for (int q = g.nq; q < kGroupJoints; ++q) g.joints[q] = g.joints[0];
+      for (int s = i; s < e; ++s) {
+        float* rec = t.brec.data() + (size_t)s * bs;
+        for (int s2 = 0; s2 < S; ++s2) {
+          for (int c = 0; c < 3; ++c) rec[c * S + s2] = t.sd[(size_t)(c * S + s2) * Vp + s];
+        }
+        for (int k = 0; k < t.KW; ++k) rec[bw + k] = t.wval[(size_t)k * Vp + s];
+        for (int q = 0; q < t.KW / 4; ++q) {
+          uint32_t w = 0;
+          for (int k = 0; k < 4; ++k) {
+            const int pair = q * 4 + k;
+            const float wv = t.wval[(size_t)pair * Vp + s];
+            const int jj = (int)((t.widx[(size_t)q * Vp + s] >> (8 * k)) & 0xffu);
+            const int ls = wv != 0.f ? local[jj] : 0;  // zero-weight padding pairs point at slot 0
+            w |= (uint32_t)ls << (8 * k);
+            if (wv != 0.f) rec[bd + ls] += wv;
+          }
+          std::memcpy(rec + bw + t.KW + q, &w, 4);
+        }
+      }
+      t.groups.push_back(g);
+      i = e;
+    }
     t.cpackB.assign(t.segments.size() * 64 * cs, 0.f);
     for (size_t sgi = 0; sgi < t.segments.size(); ++sgi)
       for (int l = 0; l < t.segments[sgi].count; ++l)
@@ -351,6 +409,12 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
       t.pair_j.push_back(pr.second);
     }
     tof(c1, t.pair_c1); tof(c2, t.pair_c2); tof(c3, t.pair_c3);
+    t.pair_c1x.assign(t.pair_c1.size(), 0.f);
+    for (int p = 0; p < np; ++p)
+      for (int aa = 0; aa < 9; ++aa)
+        for (int x = 0; x < S; ++x)
+          for (int y = 0; y < S; ++y)
+            t.pair_c1x[(((size_t)p * S + x) * 9 + aa) * S + y] = t.pair_c1[(((size_t)p * 9 + aa) * S + x) * S + y];
     tof(g0, t.diag_g0); tof(dc2, t.diag_c2); tof(dc3, t.diag_c3);
   }
 

@@ -28,6 +28,15 @@ struct Segment {
   int32_t start, count, part;
 };
 
+// Vertex group of the batch-major ("lane = instance") vertex kernels: a run of sorted slots of ONE part
+// whose skinning joints number at most kGroupJoints; the group's joint list is staged once per
+// workgroup and the per-vertex records address it by local slot.
+constexpr int kGroupJoints = 12;
+struct VertexGroup {
+  int32_t start, count, part, used, nq;
+  int32_t joints[kGroupJoints];  // padded with joints[0]
+};
+
 struct HostTables {
   int V = 0, J = 0, S = 0, P = 0;  // S counts every shape unknown: betas + kid
   int n_kid = 0;                   // 1 if the last unknown is the kid blend shape
@@ -90,6 +99,18 @@ struct HostTables {
   // slots; blob per tile = [64 x cstride() vertex records | 16 x 64 MFMA A-operand weights
   // (step t, lane l -> weight of vertex 4t + l/16 for joint slot l%16) | 16 joint ids (pad = J)]
   std::vector<Segment> gtiles;
+  // batch-major kernels: vertex groups and per-slot records = cpackA rows whose index words hold the
+  // LOCAL joint slots of the group (byte k = slot of the k-th skinning pair), and the dense weights over
+  // the group's joint list
+  std::vector<VertexGroup> groups;
+  std::vector<float> pair_c1x;   // pair_c1 re-laid out as (np, S [x], 3 [a], 3 [a'], S [y]) for the batch-major kernel
+  // brec row (brec_stride() floats, fetched with scalar loads): [sd_x : S][sd_y : S][sd_z : S][pad to a
+  // multiple of 4][KW weights][KW/4 words of local joint slots][pad to 4][dense weights over the group's
+  // joint list : kGroupJoints]
+  std::vector<float> brec;       // (Vp, brec_stride())
+  int brec_w() const { return (3 * S + 3) / 4 * 4; }                   // offset of the weights
+  int brec_d() const { return brec_w() + (KW + KW / 4 + 3) / 4 * 4; }  // offset of the dense weights
+  int brec_stride() const { return brec_d() + kGroupJoints; }
   std::vector<float> gblob;      // (ngt, gblob_stride())
   int gblob_stride() const { return 64 * cstride() + 16 * 64 + 16; }
 

@@ -60,7 +60,14 @@ struct DevModel {
   const int32_t *reg_start, *reg_slot;
   const float* reg_val;
   const float* reg_rowsum;
+  // batch-major vertex kernels (HostTables::groups / brec / bwd)
+  int ngroups, ngroups_used;
+  const int32_t* groups;  // (ngroups, kGroupRec): start, count, part, used, nq, joints[12]
+  const float* brec;
+  const float* pair_c1x;
 };
+
+constexpr int kGroupRec = 5 + sf::kGroupJoints;
 
 }  // namespace
 
@@ -131,6 +138,12 @@ struct Workspace {
   float* mbj;      // (B,J,3) per-joint residual moments (pair-Gram form)
   float* scale;    // (B) scale_corr of the known-shape fit
   float* regref;   // (B,S) ridge reference of the warm-started fit
+  // batch-major path: streams with the instance index innermost (lane = instance reads coalesce)
+  float* vpT;      // (Mp/64, 3*Vp, 64) v_posed, written by the GEMM
+  float* tT;       // (Mp/64, 3*Vp, 64) centred targets, transposed from tvs
+  float* psumP;    // (ngroups, 16, Mp) part sums per vertex group
+  float* resP;     // (ngroups, kResRec, Mp) residual-pass sums per vertex group
+  float* gramP;    // (kGramChunks, NG, Mp) pair-Gram partial sums
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -167,6 +180,11 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w) {
   ws.mbj = (float*)take((size_t)B * J * 3 * 4);
   ws.scale = (float*)take((size_t)B * 4);
   ws.regref = (float*)take((size_t)B * S * 4);
+  ws.vpT = (float*)take(Mp * 3 * Vp * 4);
+  ws.tT = (float*)take(Mp * 3 * Vp * 4);
+  ws.psumP = (float*)take((size_t)t.groups.size() * 16 * Mp * 4);
+  ws.resP = (float*)take((size_t)t.groups.size() * (16 + 3 * sf::kGroupJoints) * Mp * 4);
+  ws.gramP = (float*)take((size_t)16 * (NE1 - 1) * Mp * 4);
   if (w) *w = ws;
   return off;
 }
@@ -532,12 +550,14 @@ constexpr int kNW = 4;  // instances (= waves) per workgroup in the vertex kerne
 // of one per 512 in the generic tiled kernel.  Bsw: (N/32, 32, Kp) pre-transposed tiles.
 // grid = (nchunk, Mp/128); workgroup y handles instances [128y, 128y+128), chunk x a run of tiles.
 // ------------------------------------------------------------------------------------------------
-template <int NK2>
+// TRANSPOSED: the MFMA operands swap roles (instances become the columns of the 32x32 result) and the
+// output is written instance-innermost, C[n][Mp] — the layout of the batch-major vertex kernels.
+template <int NK2, bool TRANSPOSED>
 __global__ __launch_bounds__(256, 2) void k_posedirs_gemm_as(const float* __restrict__ A,
                                                           const float* __restrict__ Bsw,
                                                           const float* __restrict__ bias,
                                                           float* __restrict__ C, int N,
-                                                          int tiles_per_chunk) {
+                                                          int tiles_per_chunk, int Mp) {
   constexpr int KP = 2 * NK2, RS = KP + 4;  // LDS row stride: +4 floats keeps 16 lanes on 16 slots
   constexpr int TILE_F4 = 32 * KP / 4;      // float4 per tile in global memory
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][32][RS]
@@ -587,23 +607,42 @@ __global__ __launch_bounds__(256, 2) void k_posedirs_gemm_as(const float* __rest
     const int buf = (t - t_begin) & 1;
     if (t + 1 < t_end) gload(t + 1);
     f32x16 acc;
-    const float bv = bias[t * 32 + l31];
+    // C layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if (TRANSPOSED) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = bv;
+      for (int r = 0; r < 16; ++r) acc[r] = bias[t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk];
+    } else {
+      const float bv = bias[t * 32 + l31];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = bv;
+    }
     const float* brow = smem + (size_t)buf * 32 * RS + l31 * RS + lk * NK2;
 #pragma unroll
     for (int q = 0; q < NK2 / 4; ++q) {
       const float4 bq = *reinterpret_cast<const float4*>(brow + 4 * q);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q], bq.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 1], bq.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 2], bq.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 3], bq.w, acc, 0, 0, 0);
+      if (TRANSPOSED) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bq.x, a[4 * q], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bq.y, a[4 * q + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bq.z, a[4 * q + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bq.w, a[4 * q + 3], acc, 0, 0, 0);
+      } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q], bq.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 1], bq.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 2], bq.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 3], bq.w, acc, 0, 0, 0);
+      }
     }
-    // C layout of 32x32: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-    float* crow = C + (size_t)m0 * N + t * 32 + l31;
+    if (TRANSPOSED) {  // batch-major: [m0 / 64][n][64]; 32 consecutive instances per half wave
+      float* ccol = C + ((size_t)(m0 >> 6) * N + t * 32) * 64 + (m0 & 63) + l31;
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      crow[(size_t)((r & 3) + 8 * (r >> 2) + 4 * lk) * N] = acc[r];
+      for (int r = 0; r < 16; ++r)
+        ccol[(size_t)((r & 3) + 8 * (r >> 2) + 4 * lk) * 64] = acc[r];
+    } else {
+      float* crow = C + (size_t)m0 * N + t * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        crow[(size_t)((r & 3) + 8 * (r >> 2) + 4 * lk) * N] = acc[r];
+    }
     if (t + 1 < t_end) sstore(buf ^ 1);
     __syncthreads();
   }
@@ -1154,6 +1193,546 @@ __global__ void k_copy(const float* __restrict__ src, float* __restrict__ dst, s
     dst[i] = src[i];
 }
 
+// ================================================================================================
+// Batch-major vertex kernels: LANE = INSTANCE.  A workgroup owns 64 consecutive instances and one
+// vertex group (HostTables::groups: a run of one part's sorted slots with <= 12 skinning joints);
+// its 4 waves split the group's vertices.  Everything that depends on the vertex only (shapedirs,
+// skinning weights, joint slots) is wave-uniform and arrives through scalar loads; everything that
+// depends on the instance (rotations, translations, betas, accumulators) lives in the lane's
+// registers or in a lane-private LDS column; the streams (v_posed, targets) are stored instance-
+// innermost so that a wave reads 256 contiguous bytes per vertex coordinate.  No cross-lane
+// reductions, no per-vertex constants in VGPRs / LDS.
+// ================================================================================================
+constexpr int kGQ = sf::kGroupJoints;
+
+// Batch-major stream layout: [instance block of 64][n][64 instances], n = c * Vp + slot.  A workgroup
+// (one instance block, one vertex group) then streams three contiguous runs per buffer.
+// targets: sorted SoA per instance [B][N] -> batch-major (N = 3 Vp; 64x64 LDS tiles)
+__global__ __launch_bounds__(256) void k_transpose_targets(const float* __restrict__ src,
+                                                           float* __restrict__ dst, int B, int N,
+                                                           int Mp) {
+  __shared__ float tile[64][65];
+  const int n0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int b = b0 + r;
+    tile[r][tx] = b < B ? src[(size_t)b * N + n0 + tx] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) dst[((size_t)blockIdx.y * N + n0 + r) * 64 + tx] = tile[tx][r];
+}
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+
+__host__ __device__ constexpr int brec_w(int S) { return (3 * S + 3) / 4 * 4; }
+__host__ __device__ constexpr int brec_d(int S, int KW) { return brec_w(S) + (KW + KW / 4 + 3) / 4 * 4; }
+__host__ __device__ constexpr int brec_stride(int S, int KW) { return brec_d(S, KW) + kGQ; }
+
+// K5 (batch-major): vertices at the solved shape + part sums against the targets, used groups only.
+// grid (ngroups_used, Mp/64), block 256.  LDS: [kGQ][12][64] joint data as 6 pairs per joint
+//   (R0,R3) (R1,R4) (R2,R5) (R6,R7) (R8, jb2+trans2) (jb0+trans0, jb1+trans1)
+// so that the blended quantities come out in the register pairs the packed-fp32 rotation wants;
+// reused as [kBW][16][64] for the wave combine.  Output: ws.psumP[g][16][Mp].
+// Per vertex: 24 ds_read2st64 + ~60 VALU (packed fp32); the vertex record is read with scalar loads
+// one vertex ahead (weights / slots) resp. right after its last use (shapedirs).
+constexpr int kBW = 8;  // waves per workgroup of the batch-major kernels (they share the staged joints)
+
+template <int S, int KW>
+__global__ __launch_bounds__(64 * kBW) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lbs_partsum_bm(DevModel m, Workspace ws, int B, int Mp, int exp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int STRIDE = sf::jd_stride(S), BW = brec_w(S), BS = brec_stride(S, KW);
+  static_assert(KW == 4, "batch-major kernels: 4 skinning pairs per vertex");
+  const int tid = threadIdx.x, lane = tid & 63;
+  // wave index as a SCALAR: everything derived from it (vertex range, record addresses) stays
+  // wave-uniform for the compiler, so the per-vertex records are fetched with s_load
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = blockIdx.x, J = m.J, Vp = m.Vp;
+  const int32_t* gr = m.groups + (size_t)g * kGroupRec;
+  const int start = gr[0], count = gr[1], nq = gr[4];
+  const int bcol = blockIdx.y * 64 + lane;           // column of the instance-innermost buffers
+  const int b = bcol < B ? bcol : B - 1;             // row of the per-instance buffers
+  const float tr0 = ws.trans[b * 3], tr1 = ws.trans[b * 3 + 1], tr2 = ws.trans[b * 3 + 2];
+  for (int q = wave; q < nq; q += kBW) {             // stage the group's joints: lane = instance
+    const int j = gr[5 + q];
+    const float* row = ws.jd + ((size_t)b * J + j) * STRIDE;
+    const float4 r0 = *reinterpret_cast<const float4*>(row);
+    const float4 r1 = *reinterpret_cast<const float4*>(row + 4);
+    const float r8 = row[8];
+    const float4 tb = *reinterpret_cast<const float4*>(ws.jb + ((size_t)b * J + j) * 4);
+    float* dst = smem + (size_t)q * 12 * 64 + lane;
+    dst[0] = r0.x; dst[64] = r0.w;        // R0 R3
+    dst[128] = r0.y; dst[192] = r1.x;     // R1 R4
+    dst[256] = r0.z; dst[320] = r1.y;     // R2 R5
+    dst[384] = r1.z; dst[448] = r1.w;     // R6 R7
+    dst[512] = r8; dst[576] = tb.z + tr2; // R8 jb2
+    dst[640] = tb.x + tr0; dst[704] = tb.y + tr1;
+  }
+  float beta[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) beta[s] = ws.beta[(size_t)b * S + s];
+  __syncthreads();
+  const int per = (count + kBW - 1) / kBW;
+  const int v0 = start + wave * per, v1 = min(v0 + per, start + count);
+  // accumulators: P0..P2 = raw rows (cols 0,1), P3 = (raw02, raw12), s22; P4 = (st0, st1), st2;
+  // P5 = (sa0, sa1), sa2
+  f2 P0 = mk2(0, 0), P1 = P0, P2 = P0, P3 = P0, P4 = P0, P5 = P0;
+  float s22 = 0.f, st2 = 0.f, sa2 = 0.f;
+  const float* vp = ws.vpT + (size_t)blockIdx.y * 3 * Vp * 64 + lane;
+  const float* tp = ws.tT + (size_t)blockIdx.y * 3 * Vp * 64 + lane;
+  const size_t cstr = (size_t)Vp * 64;  // coordinate stride inside the instance block
+  // Software pipeline, 3 stages per iteration v:  the streams of vertex v+2 are requested (vector
+  // loads, consumed one iteration later: a full iteration of latency cover per wave, x 6 waves/SIMD),
+  // vertex v+1 is prepared from its streams + its record (scalar loads) down to 13 carried registers
+  // (shaped rest position, target, LDS offsets of its 4 joints, weights), vertex v is blended from
+  // LDS, posed and accumulated.
+  struct Raw { float x0, x1, x2, t0, t1, t2; };
+  auto fetch = [&](int v) {
+    size_t o = (size_t)v * 64;
+    if (exp == 1 || exp == 5) o = (size_t)(v & 7) * 64;  // ablation: streams L2-hot
+    Raw r;
+    r.x0 = vp[o]; r.x1 = vp[o + cstr]; r.x2 = vp[o + 2 * cstr];
+    r.t0 = tp[o]; r.t1 = tp[o + cstr]; r.t2 = tp[o + 2 * cstr];
+    return r;
+  };
+  auto prep = [&](int v, const Raw& r, f2& vs01, float& vs2, f2& t01, float& t2, int (&off)[4],
+                  float (&wq)[4]) {
+    t01 = mk2(r.t0, r.t1);
+    t2 = r.t2;
+    const float* rec = m.brec + (size_t)((exp == 3 || exp == 5) ? v0 : v) * BS;  // wave-uniform -> scalar loads
+    f2 vz = mk2(r.x2, 0.f);
+    f2 vx = mk2(r.x0, 0.f), vy = mk2(r.x1, 0.f);
+#pragma unroll
+    for (int s2 = 0; s2 + 1 < S; s2 += 2) {  // beta pairs against the per-coordinate shapedirs rows
+      const f2 bp = mk2(beta[s2], beta[s2 + 1]);
+      vx += mk2(rec[s2], rec[s2 + 1]) * bp;
+      vy += mk2(rec[S + s2], rec[S + s2 + 1]) * bp;
+      vz += mk2(rec[2 * S + s2], rec[2 * S + s2 + 1]) * bp;
+    }
+    if (S & 1) {
+      vx.x += rec[S - 1] * beta[S - 1];
+      vy.x += rec[2 * S - 1] * beta[S - 1];
+      vz.x += rec[3 * S - 1] * beta[S - 1];
+    }
+    vs01 = mk2(vx.x + vx.y, vy.x + vy.y);
+    vs2 = vz.x + vz.y;
+    const uint32_t slots = __float_as_uint(rec[BW + 4]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      off[k] = lane + (int)((slots >> (8 * k)) & 0xffu) * (12 * 64);
+      wq[k] = rec[BW + k];
+    }
+  };
+  if (v0 < v1) {
+    f2 vs01, t01;
+    float vs2, t2, wq[4];
+    int off[4];
+    const int vl = v1 - 1;  // prefetches are clamped to the last vertex (harmless re-reads)
+    prep(v0, fetch(v0), vs01, vs2, t01, t2, off, wq);
+    // two raw-stream buffers used alternately (no register copies: a copy would make the compiler
+    // wait for the loads at the end of the very iteration that issued them)
+    Raw rA, rB = fetch(min(v0 + 1, vl));
+    auto step = [&](int v, const Raw& use, Raw& fill) {
+      fill = fetch(min(v + 2, vl));
+      // blend of the 4 joints: 6 register pairs
+      f2 Q0 = mk2(0, 0), Q1 = Q0, Q2 = Q0, Q3 = Q0, Q4 = Q0, Q5 = Q0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if ((exp == 2 || exp == 5) && k > 0) break;  // ablation: one joint instead of four
+        const float* src = smem + off[k];
+        const float w = wq[k];
+        Q0 += w * mk2(src[0], src[64]);
+        Q1 += w * mk2(src[128], src[192]);
+        Q2 += w * mk2(src[256], src[320]);
+        Q3 += w * mk2(src[384], src[448]);
+        Q4 += w * mk2(src[512], src[576]);
+        Q5 += w * mk2(src[640], src[704]);
+      }
+      const f2 cs01 = vs01, ct01 = t01;
+      const float cs2 = vs2, ct2 = t2;
+      prep(min(v + 1, vl), use, vs01, vs2, t01, t2, off, wq);
+      // posed vertex (translation already folded into the staged jb)
+      const f2 a01 = (Q0 * cs01.x + Q1 * cs01.y) + (Q2 * cs2 + Q5);
+      const float a2 = (Q3.x * cs01.x + Q3.y * cs01.y) + (Q4.x * cs2 + Q4.y);
+      // part sums (_part_sums, bodyfitter.py:257-280), unit weights
+      P0 += ct01.x * a01;
+      P1 += ct01.y * a01;
+      P2 += ct2 * a01;
+      P3 += ct01 * a2;
+      s22 += ct2 * a2;
+      P4 += ct01;
+      st2 += ct2;
+      P5 += a01;
+      sa2 += a2;
+    };
+    int v = v0;
+    if (exp == 4) v = v1;  // ablation: staging + combine only
+    for (; v + 1 < v1; v += 2) {
+      step(v, rB, rA);
+      step(v + 1, rA, rB);
+    }
+    if (v < v1) step(v, rB, rA);
+  }
+  const float acc[sf::kPsum] = {P0.x, P0.y, P3.x, P1.x, P1.y, P3.y, P2.x, P2.y, s22,
+                                P4.x, P4.y, st2, P5.x, P5.y, sa2, (float)max(v1 - v0, 0)};
+  // combine the waves in a fixed order (deterministic), wave 0 writes
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < sf::kPsum; ++k) smem[(wave * sf::kPsum + k) * 64 + lane] = acc[k];
+  __syncthreads();
+  if (wave == 0) {
+    float* out = ws.psumP + (size_t)g * sf::kPsum * Mp + bcol;
+#pragma unroll
+    for (int k = 0; k < sf::kPsum; ++k) {
+      float sum = smem[k * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < kBW; ++w) sum += smem[(w * sf::kPsum + k) * 64 + lane];
+      out[(size_t)k * Mp] = sum;
+    }
+  }
+}
+
+// K3 (batch-major, unit weights): residual pass of the pair-Gram form over ALL vertex groups.
+//   b_v = t_v - (Rt_v v_posed_v + T0_v);  Sb = sum b;  r1 = sum_v S_v^T (Rt_v^T b_v);
+//   mb_q = sum_v w_vq b_v for the group's joint slots q (dense weights of the record).
+// grid (ngroups, Mp/64), block 64*kBW.  LDS joint data as in k_lbs_partsum_bm with T0 in place of jb.
+// Output: ws.resP[g][kResRec][Mp] = [r1 : S][Sb : 3][mb : 12 x 3].
+constexpr int kResRec = 16 + 3 * kGQ;  // S <= 13 + 3 here (S = 10 / 11); padded record
+
+template <int S>
+__global__ __launch_bounds__(64 * kBW) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_residual_bm(
+    DevModel m, Workspace ws, int B, int Mp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int KW = 4, STRIDE = sf::jd_stride(S), BW = brec_w(S), BD = brec_d(S, KW),
+                BS = brec_stride(S, KW);
+  static_assert(S % 2 == 0 && S + 3 <= 16, "batch-major residual kernel: even S <= 12");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = blockIdx.x, J = m.J, Vp = m.Vp;
+  const int32_t* gr = m.groups + (size_t)g * kGroupRec;
+  const int start = gr[0], count = gr[1], nq = gr[4];
+  const int bcol = blockIdx.y * 64 + lane;
+  const int b = bcol < B ? bcol : B - 1;
+  for (int q = wave; q < nq; q += kBW) {
+    const int j = gr[5 + q];
+    const float* row = ws.jd + ((size_t)b * J + j) * STRIDE;
+    const float4 r0 = *reinterpret_cast<const float4*>(row);
+    const float4 r1 = *reinterpret_cast<const float4*>(row + 4);
+    const float4 r2 = *reinterpret_cast<const float4*>(row + 8);  // R8, T0
+    float* dst = smem + (size_t)q * 12 * 64 + lane;
+    dst[0] = r0.x; dst[64] = r0.w;        // R0 R3
+    dst[128] = r0.y; dst[192] = r1.x;     // R1 R4
+    dst[256] = r0.z; dst[320] = r1.y;     // R2 R5
+    dst[384] = r1.z; dst[448] = r1.w;     // R6 R7
+    dst[512] = r2.x; dst[576] = r2.w;     // R8 T0z
+    dst[640] = r2.y; dst[704] = r2.z;     // T0x T0y
+  }
+  __syncthreads();
+  const int per = (count + kBW - 1) / kBW;
+  const int v0 = start + wave * per, v1 = min(v0 + per, start + count);
+  f2 r1p[S / 2], sb01 = mk2(0, 0), m01[kGQ];
+  float sb2 = 0.f, m2[kGQ];
+#pragma unroll
+  for (int k = 0; k < S / 2; ++k) r1p[k] = mk2(0, 0);
+#pragma unroll
+  for (int q = 0; q < kGQ; ++q) {
+    m01[q] = mk2(0, 0);
+    m2[q] = 0.f;
+  }
+  const float* vp = ws.vpT + (size_t)blockIdx.y * 3 * Vp * 64 + lane;
+  const float* tp = ws.tT + (size_t)blockIdx.y * 3 * Vp * 64 + lane;
+  const size_t cstr = (size_t)Vp * 64;
+  struct Raw { float x0, x1, x2, t0, t1, t2; };
+  auto fetch = [&](int v) {
+    const size_t o = (size_t)v * 64;
+    Raw r;
+    r.x0 = vp[o]; r.x1 = vp[o + cstr]; r.x2 = vp[o + 2 * cstr];
+    r.t0 = tp[o]; r.t1 = tp[o + cstr]; r.t2 = tp[o + 2 * cstr];
+    return r;
+  };
+  auto slots_of = [&](int v, int (&off)[4], float (&wq)[4]) {
+    const float* rec = m.brec + (size_t)v * BS;  // wave-uniform -> scalar loads
+    const uint32_t slots = __float_as_uint(rec[BW + 4]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      off[k] = lane + (int)((slots >> (8 * k)) & 0xffu) * (12 * 64);
+      wq[k] = rec[BW + k];
+    }
+  };
+  if (v0 < v1) {
+    const int vl = v1 - 1;
+    int off[4];
+    float wq[4];
+    slots_of(v0, off, wq);
+    Raw rA = fetch(v0), rB = fetch(min(v0 + 1, vl));
+    auto step = [&](int v, const Raw& cur, Raw& fill) {
+      // blend of the 4 joints: (R0,R3) (R1,R4) (R2,R5) (R6,R7) (R8,T0z) (T0x,T0y)
+      f2 Q0 = mk2(0, 0), Q1 = Q0, Q2 = Q0, Q3 = Q0, Q4 = Q0, Q5 = Q0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float* src = smem + off[k];
+        const float w = wq[k];
+        Q0 += w * mk2(src[0], src[64]);
+        Q1 += w * mk2(src[128], src[192]);
+        Q2 += w * mk2(src[256], src[320]);
+        Q3 += w * mk2(src[384], src[448]);
+        Q4 += w * mk2(src[512], src[576]);
+        Q5 += w * mk2(src[640], src[704]);
+      }
+      const float* rec = m.brec + (size_t)v * BS;  // shapedirs + dense weights of THIS vertex
+      slots_of(min(v + 1, vl), off, wq);           // joint slots of the next one
+      // residual
+      const f2 pos01 = (Q0 * cur.x0 + Q1 * cur.x1) + (Q2 * cur.x2 + Q5);
+      const float pos2 = (Q3.x * cur.x0 + Q3.y * cur.x1) + (Q4.x * cur.x2 + Q4.y);
+      const f2 b01 = mk2(cur.t0, cur.t1) - pos01;
+      const float b2 = cur.t2 - pos2;
+      fill = fetch(min(v + 2, vl));
+      sb01 += b01;
+      sb2 += b2;
+      // u = Rt^T b
+      const float u0 = (Q0.x * b01.x + Q0.y * b01.y) + Q3.x * b2;
+      const float u1 = (Q1.x * b01.x + Q1.y * b01.y) + Q3.y * b2;
+      const float u2 = (Q2.x * b01.x + Q2.y * b01.y) + Q4.x * b2;
+#pragma unroll
+      for (int k = 0; k < S / 2; ++k)
+        r1p[k] += (mk2(rec[2 * k], rec[2 * k + 1]) * u0 + mk2(rec[S + 2 * k], rec[S + 2 * k + 1]) * u1) +
+                  mk2(rec[2 * S + 2 * k], rec[2 * S + 2 * k + 1]) * u2;
+#pragma unroll
+      for (int q = 0; q < kGQ; ++q) {
+        const float wd = rec[BD + q];
+        m01[q] += wd * b01;
+        m2[q] += wd * b2;
+      }
+    };
+    int v = v0;
+    for (; v + 1 < v1; v += 2) {
+      step(v, rA, rA);      // rA is consumed before it is refilled with vertex v + 2
+      step(v + 1, rB, rB);
+    }
+    if (v < v1) step(v, rA, rA);
+  }
+  // combine the waves in a fixed order, 16 values per pass through the (reused) staging region
+  float vals[kResRec];
+#pragma unroll
+  for (int k = 0; k < S / 2; ++k) {
+    vals[2 * k] = r1p[k].x;
+    vals[2 * k + 1] = r1p[k].y;
+  }
+  vals[S] = sb01.x; vals[S + 1] = sb01.y; vals[S + 2] = sb2;
+#pragma unroll
+  for (int k = S + 3; k < 16; ++k) vals[k] = 0.f;
+#pragma unroll
+  for (int q = 0; q < kGQ; ++q) {
+    vals[16 + 3 * q] = m01[q].x;
+    vals[16 + 3 * q + 1] = m01[q].y;
+    vals[16 + 3 * q + 2] = m2[q];
+  }
+  float* out = ws.resP + (size_t)g * kResRec * Mp + bcol;
+#pragma unroll
+  for (int pass = 0; pass < (kResRec + 15) / 16; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (pass * 16 + k < kResRec) smem[(wave * 16 + k) * 64 + lane] = vals[pass * 16 + k];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        if (pass * 16 + k >= kResRec) break;
+        float sum = smem[k * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < kBW; ++w) sum += smem[(w * 16 + k) * 64 + lane];
+        out[(size_t)(pass * 16 + k) * Mp] = sum;
+      }
+    }
+  }
+}
+
+// K3g (batch-major): pair-Gram of sf::pair_gram_stage with lane = instance.  Work units = the np joint
+// pairs followed by the J diagonal joints; a wave takes a contiguous run of units for its 64
+// instances and accumulates the NG upper-triangle entries in registers; all model constants
+// (c1: 9 S^2 per pair) arrive through scalar loads.  grid (kGramChunks, Mp/64), block 64.
+// Output: ws.gramP[chunk][NG][Mp].
+constexpr int kGramChunks = 16;
+
+template <int S>
+__global__ __launch_bounds__(64) void k_pair_gram_bm(DevModel m, Workspace ws, int B, int Mp) {
+  constexpr int STRIDE = sf::jd_stride(S), ROW = sf::jd_row(S), NG = sf::ne_ng(S), NC1 = 9 * S * S;
+  constexpr int NLD = (NC1 + 63) / 64;
+  // the pair's 9 S^2 constants go through LDS (coalesced load, broadcast reads): as scalar loads the
+  // compiler hoists all of them and spills SGPRs by the thousand
+  __shared__ __attribute__((aligned(16))) float c1s[2][NLD * 64];
+  const int lane = threadIdx.x, J = m.J, np = m.jt.np;
+  const int bcol = blockIdx.y * 64 + lane;
+  const int b = bcol < B ? bcol : B - 1;
+  const int nunits = np + J;
+  const int per = (nunits + kGramChunks - 1) / kGramChunks;
+  const int u0 = blockIdx.x * per, u1 = min(u0 + per, nunits);
+  float G[NG];
+#pragma unroll
+  for (int e = 0; e < NG; ++e) G[e] = 0.f;
+  const float* jdb = ws.jd + (size_t)b * J * STRIDE;
+  auto load_RD = [&](int j, float (&R)[9], float (&D)[3 * S]) {  // R_j and D_j = R_j^T T'_j
+    const float* row = jdb + (size_t)j * STRIDE;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = row[k];
+    float T[3 * S];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int i = 0; i < S; ++i) T[c * S + i] = row[12 + c * ROW + i];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int i = 0; i < S; ++i)
+        D[a * S + i] = (R[a] * T[i] + R[3 + a] * T[S + i]) + R[6 + a] * T[2 * S + i];
+  };
+  float nx[NLD];  // the next pair's constants on their way to LDS
+  auto c1_fetch = [&](int u) {
+    const float* src = m.pair_c1x + (size_t)(u < np ? u : 0) * NC1;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) nx[k] = (k * 64 + lane < NC1) ? src[k * 64 + lane] : 0.f;
+  };
+  auto c1_commit = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) c1s[buf][k * 64 + lane] = nx[k];
+  };
+  if (u0 < u1) {
+    c1_fetch(u0);
+    c1_commit(0);
+  }
+  for (int u = u0; u < u1; ++u) {
+    const int buf = (u - u0) & 1;
+    if (u + 1 < u1) c1_fetch(u + 1);
+    if (u < np) {
+      const int j1 = m.jt.pair_j[2 * u], j2 = m.jt.pair_j[2 * u + 1];
+      float R1[9], R2[9], D1[3 * S], D2[3 * S];
+      load_RD(j1, R1, D1);
+      load_RD(j2, R2, D2);
+      float Q[9];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int a2 = 0; a2 < 3; ++a2)
+          Q[a * 3 + a2] = (R1[a] * R2[a2] + R1[3 + a] * R2[3 + a2]) + R1[6 + a] * R2[6 + a2];
+      const float* c1 = c1s[buf];                          // [x][a][a'][y], uniform addresses
+      const float* c2 = m.jt.pair_c2 + (size_t)u * 3 * S;  // wave-uniform -> scalar loads
+      const float c3 = m.jt.pair_c3[u];
+      float U[3 * S], V[3 * S];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int y = 0; y < S; ++y) {
+          const float uu = (Q[a * 3] * D2[y] + Q[a * 3 + 1] * D2[S + y]) + Q[a * 3 + 2] * D2[2 * S + y];
+          U[a * S + y] = uu;
+          V[a * S + y] = ((Q[a * 3] * c2[y] + Q[a * 3 + 1] * c2[S + y]) + Q[a * 3 + 2] * c2[2 * S + y]) + c3 * uu;
+        }
+#pragma unroll
+      for (int x = 0; x < S; ++x) {
+        float f[S];
+#pragma unroll
+        for (int y = 0; y < S; ++y) f[y] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const float* cx = c1 + (x * 3 + a) * 3 * S;  // 3 x S constants of this (x, a)
+          const float c2x = c2[a * S + x], d1x = D1[a * S + x];
+#pragma unroll
+          for (int y = 0; y < S; ++y)
+            f[y] += ((Q[a * 3] * cx[y] + Q[a * 3 + 1] * cx[S + y]) + Q[a * 3 + 2] * cx[2 * S + y]) +
+                    (c2x * U[a * S + y] + d1x * V[a * S + y]);
+        }
+        // G[i][i2] (i <= i2) collects f[i][i2] + f[i2][i]
+#pragma unroll
+        for (int y = 0; y < S; ++y)
+          G[sf::ne_g(S, x < y ? x : y, x < y ? y : x)] += (x == y) ? 2.f * f[y] : f[y];
+      }
+    } else {
+      const int j = u - np;
+      float R[9], D[3 * S];
+      load_RD(j, R, D);
+      const float* c2 = m.jt.diag_c2 + (size_t)j * 3 * S;
+      const float c3 = m.jt.diag_c3[j];
+#pragma unroll
+      for (int i = 0; i < S; ++i)
+#pragma unroll
+        for (int i2 = i; i2 < S; ++i2) {
+          float acc = 0.f;
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+            acc += c2[a * S + i] * D[a * S + i2] + D[a * S + i] * (c2[a * S + i2] + c3 * D[a * S + i2]);
+          G[sf::ne_g(S, i, i2)] += acc;
+        }
+    }
+    if (u + 1 < u1) c1_commit(buf ^ 1);
+  }
+  float* out = ws.gramP + (size_t)blockIdx.x * NG * Mp + bcol;
+#pragma unroll
+  for (int e = 0; e < NG; ++e) out[(size_t)e * Mp] = G[e];
+}
+
+// K3c: partial sums of the two kernels above -> the normal-equation record the solve stage reads
+// (gramv: G | r1 | SA = 0 (closed form in the joint stage) | Sb | W = V) and the per-joint residual
+// moments ws.mbj.  grid (ceil(B/256), S + 3 + 3 J + NG): blockIdx.y = output element.
+template <int S>
+__global__ __launch_bounds__(256) void k_gram_combine_bm(DevModel m, Workspace ws, int B, int Mp) {
+  constexpr int NG = sf::ne_ng(S), NE = sf::ne_size(S);
+  const int b = blockIdx.x * 256 + threadIdx.x, e = blockIdx.y, J = m.J;
+  if (b >= B) return;
+  double* out = ws.gramv + (size_t)b * (NE + 1);
+  if (e < S + 3) {  // r1 / Sb: groups in table order
+    float acc = 0.f;
+    for (int g = 0; g < m.ngroups; ++g) acc += ws.resP[((size_t)g * kResRec + e) * Mp + b];
+    out[e < S ? NG + e : NG + 4 * S + (e - S)] = (double)acc;
+    if (e == 0) {
+      for (int k = 0; k < 3 * S; ++k) out[NG + S + k] = 0.0;
+      out[NE] = (double)m.V;  // w_sum = num_vertices (bodyfitter.py:1038-1040)
+    }
+  } else if (e < S + 3 + 3 * J) {  // residual moment of joint j, coordinate c
+    const int j = (e - S - 3) / 3, c = (e - S - 3) % 3;
+    float acc = 0.f;
+    for (int g = 0; g < m.ngroups; ++g) {
+      const int32_t* gr = m.groups + (size_t)g * kGroupRec;
+      const int nq = gr[4];
+      for (int q = 0; q < nq; ++q)
+        if (gr[5 + q] == j) acc += ws.resP[((size_t)g * kResRec + 16 + 3 * q + c) * Mp + b];
+    }
+    ws.mbj[((size_t)b * J + j) * 3 + c] = acc;
+  } else {  // Gramian entry: instance-independent part + the chunks of the pair kernel
+    const int k = e - (S + 3 + 3 * J);
+    int i = 0, r = k;
+    while (r >= S - i) {
+      r -= S - i;
+      ++i;
+    }
+    float acc = m.jt.diag_g0[i * S + i + r];
+    for (int ch = 0; ch < kGramChunks; ++ch) acc += ws.gramP[((size_t)ch * NG + k) * Mp + b];
+    out[k] = (double)acc;
+  }
+}
+
+// part sums of the vertex groups -> ws.psum[b][part][16] (groups of one part summed in table order).
+// grid (ceil(B/256), J): blockIdx.y = part.
+__global__ __launch_bounds__(256) void k_psum_combine(DevModel m, Workspace ws, int B, int Mp) {
+  const int b = blockIdx.x * 256 + threadIdx.x, part = blockIdx.y;
+  if (b >= B) return;
+  float acc[sf::kPsum];
+#pragma unroll
+  for (int k = 0; k < sf::kPsum; ++k) acc[k] = 0.f;
+  bool any = false;
+  for (int g = 0; g < m.ngroups_used; ++g) {
+    if (m.groups[(size_t)g * kGroupRec + 2] != part) continue;
+    any = true;
+#pragma unroll
+    for (int k = 0; k < sf::kPsum; ++k) acc[k] += ws.psumP[((size_t)g * sf::kPsum + k) * Mp + b];
+  }
+  if (!any) return;
+  float4* dst = reinterpret_cast<float4*>(ws.psum + ((size_t)b * m.J + part) * sf::kPsum);
+  dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+  dst[2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
+  dst[3] = make_float4(acc[12], acc[13], acc[14], acc[15]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
@@ -1167,6 +1746,22 @@ bool use_pair_form() {
     return e && std::string(e) == "pair";
   }();
   return pair;
+}
+
+// batch-major vertex kernels (SMPLFIT_BM=1): unit vertex weights, joints given, SMPL-sized GEMM
+bool use_bm() {
+  const char* e = getenv("SMPLFIT_BM");
+  return e && e[0] == '1';
+}
+
+template <int S, int KW>
+void launch_lbs_bm(const DevModel& d, const Workspace& ws, int B, hipStream_t st) {
+  const int Mp = (int)align_up((size_t)B, 128);
+  const size_t lds = (size_t)kGQ * 12 * 64 * 4;
+  if constexpr (KW == 4)
+    hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4>), dim3(d.ngroups_used, Mp / 64), dim3(64 * kBW), lds, st, d, ws, B, Mp,
+                       getenv("SMPLFIT_EXP") ? atoi(getenv("SMPLFIT_EXP")) : 0);
+  hipLaunchKernelGGL(k_psum_combine, dim3((B + 255) / 256, d.J), dim3(256), 0, st, d, ws, B, Mp);
 }
 
 template <int S, int KW>
@@ -1260,8 +1855,10 @@ int check_common(const smplfit_handle* h, int batch, void* workspace, size_t wor
   return 0;
 }
 
-int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st) {
+int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, bool transposed = false) {
   const int Mp = (int)align_up((size_t)B, 128), N = 3 * d.Vp;
+  if (transposed && d.Kp != 208)
+    return fail(SMPLFIT_ERR_UNSUPPORTED, "batch-major path: only the A-stationary GEMM (Kp == 208)");
   if (d.Kp == 208) {  // SMPL (J = 24): A-stationary kernel, 104 A registers per lane
     constexpr int NK2 = 104;
     const int ntiles = N / 32;
@@ -1271,8 +1868,12 @@ int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st) {
     const int per = (ntiles + nchunk - 1) / nchunk;
     nchunk = (ntiles + per - 1) / per;
     const size_t lds = (size_t)2 * 32 * (2 * NK2 + 4) * 4;
-    hipLaunchKernelGGL((k_posedirs_gemm_as<NK2>), dim3(nchunk, Mp / 128), dim3(256), lds, st, ws.rp,
-                       d.pdSw, d.vtN, ws.vposed, N, per);
+    if (transposed)
+      hipLaunchKernelGGL((k_posedirs_gemm_as<NK2, true>), dim3(nchunk, Mp / 128), dim3(256), lds, st,
+                         ws.rp, d.pdSw, d.vtN, ws.vpT, N, per, Mp);
+    else
+      hipLaunchKernelGGL((k_posedirs_gemm_as<NK2, false>), dim3(nchunk, Mp / 128), dim3(256), lds, st,
+                         ws.rp, d.pdSw, d.vtN, ws.vposed, N, per, Mp);
     return 0;
   }
   hipLaunchKernelGGL(k_posedirs_gemm, dim3((N / 128) * (Mp / 128)), dim3(256), 0, st, ws.rp, d.pdT,
@@ -1319,6 +1920,11 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   const bool eff_v = joints ? (vw && jw) : (vw != nullptr);
   const bool eff_j = joints && vw && jw;
   launch_center_sort(d, tv, tj, vw, ws, B, st);
+  const bool bm = use_bm() && joints && !vw && d.Kp == 208 && d.KW == 4 && d.S == 10 && !o.rotations_only;
+  if (bm) {
+    const int Mp = (int)align_up((size_t)B, 128), N = 3 * d.Vp;
+    hipLaunchKernelGGL(k_transpose_targets, dim3(N / 64, Mp / 64), dim3(256), 0, st, ws.tvs, ws.tT, B, N, Mp);
+  }
   const float* tj_rot = ws.tjc;
   if (!joints) {  // regressed target joints from the centred vertices (bodyfitter.py:1342-1344)
     hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(64), 0, st, d, ws.tvs, ws.tjreg);
@@ -1369,17 +1975,33 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     return post_launch_check();
   }
   for (int it = 0; it < o.num_iter; ++it) {
-    launch_gemm(d, ws, B, st);
+    if (bm) {
+      // batch-major vertex block: one transposed GEMM feeds the residual pass and, after the solve,
+      // the LBS / part-sum pass of this iteration
+      const int Mp = (int)align_up((size_t)B, 128);
+      launch_gemm(d, ws, B, st, true);
+      const size_t lds = (size_t)kGQ * 12 * 64 * 4;
+      hipLaunchKernelGGL((k_residual_bm<10>), dim3(d.ngroups, Mp / 64), dim3(64 * kBW), lds, st, d, ws, B, Mp);
+      hipLaunchKernelGGL((k_pair_gram_bm<10>), dim3(kGramChunks, Mp / 64), dim3(64), 0, st, d, ws, B, Mp);
+      hipLaunchKernelGGL((k_gram_combine_bm<10>), dim3((B + 255) / 256, 10 + 3 + 3 * d.J + sf::ne_ng(10)),
+                         dim3(256), 0, st, d, ws, B, Mp);
+    } else {
+      launch_gemm(d, ws, B, st);
 #define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, B, eff_v, st)
-    SF_DISPATCH_SKW(d, SF_CALL_ACCUM);
+      SF_DISPATCH_SKW(d, SF_CALL_ACCUM);
 #undef SF_CALL_ACCUM
+    }
     // K4 stays its own launch: fused into the prologue of the LBS kernel (template flag SOLVE) its
     // ~40 serial barriers stall all four waves of the workgroup and the kernel ran 230 us longer
     hipLaunchKernelGGL(k_shape_solve, dim3(B), dim3(64), solve_lds(d), st, d, ws, o.beta_reg,
-                       o.beta_reg2, o.kid_reg, (!eff_v && use_pair_form()) ? 1 : 0, use_ref);
+                       o.beta_reg2, o.kid_reg, (bm || (!eff_v && use_pair_form())) ? 1 : 0, use_ref);
     const bool last = it + 1 == o.num_iter;
     if (last && !o.final_adjust) break;  // nothing consumes the re-evaluated mesh
-    if (joints) {
+    if (bm) {
+#define SF_CALL_LBS(S_, KW_) launch_lbs_bm<S_, KW_>(d, ws, B, st)
+      SF_DISPATCH_SKW(d, SF_CALL_LBS);
+#undef SF_CALL_LBS
+    } else if (joints) {
 #define SF_CALL_LBS(S_, KW_) \
   launch_lbs<S_, KW_, 0, false>(d, ws, B, vweighted, d.S, ws.beta, ws.trans, nullptr, 0.f, 0.f, st)
       SF_DISPATCH_SKW(d, SF_CALL_LBS);
@@ -1616,6 +2238,20 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
   up(t.reg_slot, &d.reg_slot);
   up(t.reg_val, &d.reg_val);
   up(t.reg_rowsum, &d.reg_rowsum);
+  {
+    std::vector<int32_t> gr;
+    d.ngroups = (int)t.groups.size();
+    d.ngroups_used = 0;
+    for (const auto& g : t.groups) {
+      gr.push_back(g.start); gr.push_back(g.count); gr.push_back(g.part); gr.push_back(g.used);
+      gr.push_back(g.nq);
+      for (int q = 0; q < sf::kGroupJoints; ++q) gr.push_back(g.joints[q]);
+      if (g.used) ++d.ngroups_used;  // used parts come first in slot order
+    }
+    up(gr, &d.groups);
+    up(t.brec, &d.brec);
+    up(t.pair_c1x, &d.pair_c1x);
+  }
   sf::JointTabs& jt = d.jt;
   jt.J = t.J; jt.S = t.S; jt.num_levels = t.num_levels(); jt.adj_last_level = t.adj_last_level;
   jt.P = t.P; jt.Kp = t.Kp;
