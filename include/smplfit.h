@@ -201,9 +201,12 @@ int smplfit_shape_solve_f32(const smplfit_handle* h, const float* glob_rotmats,
  * the same batch left behind.  Synchronises the stream (it is a measurement, not a product call). */
 enum smplfit_kernel_id {
   SMPLFIT_KERNEL_POSEDIRS_GEMM = 2, /* K2 v_posed = v_template + pose_feature . posedirs          */
-  SMPLFIT_KERNEL_SHAPE_ACCUM = 3,   /* K3 vertex block of the normal equations                    */
+  SMPLFIT_KERNEL_SHAPE_ACCUM = 3,   /* K3 vertex block of the normal equations (batch-major path:
+                                       the residual pass k_residual_bm)                            */
   SMPLFIT_KERNEL_SHAPE_SOLVE = 4,   /* K4 fp64 Cholesky solve                                      */
   SMPLFIT_KERNEL_LBS_PARTSUM = 5,   /* K5 vertices at the solution + part sums                     */
+  SMPLFIT_KERNEL_PAIR_GRAM = 6,     /* batch-major path: Gramian from the rotations (k_pair_gram_bm) */
+  SMPLFIT_KERNEL_TRANSPOSE = 7,     /* batch-major path: targets to the instance-innermost layout  */
 };
 int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, int reps,
                             void* workspace, size_t workspace_bytes, void* hip_stream,

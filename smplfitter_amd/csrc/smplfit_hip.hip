@@ -184,7 +184,7 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w) {
   ws.tT = (float*)take(Mp * 3 * Vp * 4);
   ws.psumP = (float*)take((size_t)t.groups.size() * 16 * Mp * 4);
   ws.resP = (float*)take((size_t)t.groups.size() * (16 + 3 * sf::kGroupJoints) * Mp * 4);
-  ws.gramP = (float*)take((size_t)16 * (NE1 - 1) * Mp * 4);
+  ws.gramP = (float*)take((size_t)32 * (NE1 - 1) * Mp * 4);  // kGramChunks x NG (<= NE) x Mp
   if (w) *w = ws;
   return off;
 }
@@ -1553,10 +1553,10 @@ __global__ __launch_bounds__(64 * kBW) __attribute__((amdgpu_waves_per_eu(4, 4))
 // instances and accumulates the NG upper-triangle entries in registers; all model constants
 // (c1: 9 S^2 per pair) arrive through scalar loads.  grid (kGramChunks, Mp/64), block 64.
 // Output: ws.gramP[chunk][NG][Mp].
-constexpr int kGramChunks = 16;
+constexpr int kGramChunks = 32;
 
 template <int S>
-__global__ __launch_bounds__(64) void k_pair_gram_bm(DevModel m, Workspace ws, int B, int Mp) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pair_gram_bm(DevModel m, Workspace ws, int B, int Mp) {
   constexpr int STRIDE = sf::jd_stride(S), ROW = sf::jd_row(S), NG = sf::ne_ng(S), NC1 = 9 * S * S;
   constexpr int NLD = (NC1 + 63) / 64;
   // the pair's 9 S^2 constants go through LDS (coalesced load, broadcast reads): as scalar loads the
@@ -1618,33 +1618,40 @@ __global__ __launch_bounds__(64) void k_pair_gram_bm(DevModel m, Workspace ws, i
       const float* c1 = c1s[buf];                          // [x][a][a'][y], uniform addresses
       const float* c2 = m.jt.pair_c2 + (size_t)u * 3 * S;  // wave-uniform -> scalar loads
       const float c3 = m.jt.pair_c3[u];
-      float U[3 * S], V[3 * S];
+      // U = Q D2, V = Q c2 + c3 U as register pairs over y (packed fp32)
+      f2 U[3][S / 2], V[3][S / 2];
 #pragma unroll
       for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int y = 0; y < S; ++y) {
-          const float uu = (Q[a * 3] * D2[y] + Q[a * 3 + 1] * D2[S + y]) + Q[a * 3 + 2] * D2[2 * S + y];
-          U[a * S + y] = uu;
-          V[a * S + y] = ((Q[a * 3] * c2[y] + Q[a * 3 + 1] * c2[S + y]) + Q[a * 3 + 2] * c2[2 * S + y]) + c3 * uu;
+        for (int k = 0; k < S / 2; ++k) {
+          const f2 uu = (Q[a * 3] * mk2(D2[2 * k], D2[2 * k + 1]) + Q[a * 3 + 1] * mk2(D2[S + 2 * k], D2[S + 2 * k + 1])) +
+                        Q[a * 3 + 2] * mk2(D2[2 * S + 2 * k], D2[2 * S + 2 * k + 1]);
+          U[a][k] = uu;
+          V[a][k] = ((Q[a * 3] * mk2(c2[2 * k], c2[2 * k + 1]) + Q[a * 3 + 1] * mk2(c2[S + 2 * k], c2[S + 2 * k + 1])) +
+                     Q[a * 3 + 2] * mk2(c2[2 * S + 2 * k], c2[2 * S + 2 * k + 1])) + c3 * uu;
         }
 #pragma unroll
       for (int x = 0; x < S; ++x) {
-        float f[S];
+        f2 f[S / 2];
 #pragma unroll
-        for (int y = 0; y < S; ++y) f[y] = 0.f;
+        for (int k = 0; k < S / 2; ++k) f[k] = mk2(0.f, 0.f);
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
           const float* cx = c1 + (x * 3 + a) * 3 * S;  // 3 x S constants of this (x, a)
           const float c2x = c2[a * S + x], d1x = D1[a * S + x];
 #pragma unroll
-          for (int y = 0; y < S; ++y)
-            f[y] += ((Q[a * 3] * cx[y] + Q[a * 3 + 1] * cx[S + y]) + Q[a * 3 + 2] * cx[2 * S + y]) +
-                    (c2x * U[a * S + y] + d1x * V[a * S + y]);
+          for (int k = 0; k < S / 2; ++k)
+            f[k] += ((Q[a * 3] * mk2(cx[2 * k], cx[2 * k + 1]) + Q[a * 3 + 1] * mk2(cx[S + 2 * k], cx[S + 2 * k + 1])) +
+                     Q[a * 3 + 2] * mk2(cx[2 * S + 2 * k], cx[2 * S + 2 * k + 1])) +
+                    (c2x * U[a][k] + d1x * V[a][k]);
         }
         // G[i][i2] (i <= i2) collects f[i][i2] + f[i2][i]
 #pragma unroll
-        for (int y = 0; y < S; ++y)
-          G[sf::ne_g(S, x < y ? x : y, x < y ? y : x)] += (x == y) ? 2.f * f[y] : f[y];
+        for (int y = 0; y < S; ++y) {
+          const float fy = (y & 1) ? f[y / 2].y : f[y / 2].x;
+          G[sf::ne_g(S, x < y ? x : y, x < y ? y : x)] += (x == y) ? 2.f * fy : fy;
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the LDS reads of one x together (register pressure)
       }
     } else {
       const int j = u - np;
@@ -1748,11 +1755,14 @@ bool use_pair_form() {
   return pair;
 }
 
-// batch-major vertex kernels (SMPLFIT_BM=1): unit vertex weights, joints given, SMPL-sized GEMM
+// Batch-major vertex kernels: the default whenever they apply (unit vertex weights, target joints
+// given, 10 betas, 4 skinning pairs per vertex, SMPL-sized GEMM); SMPLFIT_BM=0 selects the
+// wave-per-instance kernels everywhere (they also serve every other configuration).
 bool use_bm() {
   const char* e = getenv("SMPLFIT_BM");
-  return e && e[0] == '1';
+  return !(e && e[0] == '0');
 }
+bool bm_applies(const DevModel& d) { return use_bm() && d.Kp == 208 && d.KW == 4 && d.S == 10; }
 
 template <int S, int KW>
 void launch_lbs_bm(const DevModel& d, const Workspace& ws, int B, hipStream_t st) {
@@ -1920,7 +1930,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   const bool eff_v = joints ? (vw && jw) : (vw != nullptr);
   const bool eff_j = joints && vw && jw;
   launch_center_sort(d, tv, tj, vw, ws, B, st);
-  const bool bm = use_bm() && joints && !vw && d.Kp == 208 && d.KW == 4 && d.S == 10 && !o.rotations_only;
+  const bool bm = bm_applies(d) && joints && !vw && !o.rotations_only;
   if (bm) {
     const int Mp = (int)align_up((size_t)B, 128), N = 3 * d.Vp;
     hipLaunchKernelGGL(k_transpose_targets, dim3(N / 64, Mp / 64), dim3(256), 0, st, ws.tvs, ws.tT, B, N, Mp);
@@ -2590,10 +2600,26 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
   hipEvent_t e0, e1;
   SF_HIP_TRY(hipEventCreate(&e0));
   SF_HIP_TRY(hipEventCreate(&e1));
+  const bool bm = bm_applies(d);  // time the kernels the default fit runs
+  const int Mp = (int)align_up((size_t)batch, 128);
   auto once = [&]() -> int {
     switch (kernel_id) {
-      case SMPLFIT_KERNEL_POSEDIRS_GEMM: return launch_gemm(d, ws, batch, st);
+      case SMPLFIT_KERNEL_POSEDIRS_GEMM: return launch_gemm(d, ws, batch, st, bm);
+      case SMPLFIT_KERNEL_PAIR_GRAM:
+        if (!bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "pair-Gram kernel: batch-major path not active");
+        hipLaunchKernelGGL((k_pair_gram_bm<10>), dim3(kGramChunks, Mp / 64), dim3(64), 0, st, d, ws, batch, Mp);
+        return 0;
+      case SMPLFIT_KERNEL_TRANSPOSE:
+        if (!bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "transpose kernel: batch-major path not active");
+        hipLaunchKernelGGL(k_transpose_targets, dim3(3 * d.Vp / 64, Mp / 64), dim3(256), 0, st, ws.tvs, ws.tT,
+                           batch, 3 * d.Vp, Mp);
+        return 0;
       case SMPLFIT_KERNEL_SHAPE_ACCUM: {
+        if (bm) {
+          hipLaunchKernelGGL((k_residual_bm<10>), dim3(d.ngroups, Mp / 64), dim3(64 * kBW),
+                             (size_t)kGQ * 12 * 64 * 4, st, d, ws, batch, Mp);
+          return 0;
+        }
 #define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, batch, false, st)
         SF_DISPATCH_SKW(d, SF_CALL_ACCUM);
 #undef SF_CALL_ACCUM
@@ -2604,6 +2630,10 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
                            use_pair_form() ? 1 : 0, 0);
         return 0;
       case SMPLFIT_KERNEL_LBS_PARTSUM: {
+        if (bm) {
+          launch_lbs_bm<10, 4>(d, ws, batch, st);
+          return 0;
+        }
 #define SF_CALL_LBS(S_, KW_) \
   launch_lbs<S_, KW_, 0, false>(d, ws, batch, false, d.S, ws.beta, ws.trans, nullptr, 0.f, 0.f, st)
         SF_DISPATCH_SKW(d, SF_CALL_LBS);
@@ -2617,8 +2647,10 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
   // before K5), so caches are in the state the kernel sees in situ; only the target kernel is
   // bracketed by the two events.
   auto pre = [&]() {
-    if (kernel_id == SMPLFIT_KERNEL_SHAPE_ACCUM) launch_gemm(d, ws, batch, st);
-    if (kernel_id == SMPLFIT_KERNEL_LBS_PARTSUM) {
+    if (kernel_id == SMPLFIT_KERNEL_SHAPE_ACCUM) launch_gemm(d, ws, batch, st, bm);
+    if (kernel_id == SMPLFIT_KERNEL_LBS_PARTSUM && bm)
+      hipLaunchKernelGGL(k_shape_solve, dim3(batch), dim3(64), solve_lds(d), st, d, ws, 1.0f, 0.0f, 1.0f, 1, 0);
+    if (kernel_id == SMPLFIT_KERNEL_LBS_PARTSUM && !bm) {
 #define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, batch, false, st)
       SF_DISPATCH_SKW(d, SF_CALL_ACCUM);
 #undef SF_CALL_ACCUM

@@ -57,8 +57,17 @@ def test_forward_goldens(name, model_root, golden, dev):
     assert 'vertices' not in j and np.abs(j['joints'] - g['fwd_joints']).max() < 2e-6
 
 
+@pytest.fixture(params=['batch-major', 'wave-per-instance'])
+def vertex_path(request, monkeypatch):
+    """The default fit takes the batch-major vertex kernels where they apply (unit vertex weights, joints
+    given, SMPL-sized model); SMPLFIT_BM=0 forces the wave-per-instance kernels.  Both must agree with
+    the reference."""
+    monkeypatch.setenv('SMPLFIT_BM', '1' if request.param == 'batch-major' else '0')
+    return request.param
+
+
 @pytest.mark.parametrize('name', ['smpl', 'smplx', 'smpl1024'])
-def test_fit_goldens(name, model_root, golden, dev):
+def test_fit_goldens(name, model_root, golden, dev, vertex_path):
     g = golden(name)
     kind, md = util.load_md(model_root, name, g)
     om64, _ = util.make_oracle(md, kind, np.float64)
@@ -115,7 +124,7 @@ def make_targets(m, B, seed, dev, noise=0.0):
 
 
 @pytest.mark.parametrize('name,B', [('smpl', 64), ('smplx', 32)])
-def test_fit_vs_oracle(name, B, model_root, golden, dev):
+def test_fit_vs_oracle(name, B, model_root, golden, dev, vertex_path):
     """Same seeded inputs through the HIP path and the CPU oracle (fp32 and fp64)."""
     g = golden(name)
     kind, md = util.load_md(model_root, name, g)
@@ -159,7 +168,7 @@ def test_edge_batches(model_root, golden, dev):
 
 
 @pytest.mark.parametrize('name,B', [('smpl', 4096), ('smplx', 4096), ('smpl1024', 16384)])
-def test_full_size_properties(name, B, model_root, golden, dev):
+def test_full_size_properties(name, B, model_root, golden, dev, vertex_path):
     """BASELINE.json configs 2-4 at full size: round trip (the reference's own acceptance test,
     tests/test_fitter_common.py:31-72: mean vertex / joint error < 5e-3 m after fit -> forward),
     run-to-run determinism (no float atomics anywhere) and batch-slice independence."""
@@ -224,7 +233,7 @@ for name, kind in (("smpl", "smpl"), ("smplx", "smplx")):
         assert np.abs(o["trans"] - ref["trans"]).max() < 1e-5, (name, c)
 print("PAIR_FORM_OK")
 '''
-    env = dict(os.environ, SMPLFIT_SHAPE_FORM='pair')
+    env = dict(os.environ, SMPLFIT_SHAPE_FORM='pair', SMPLFIT_BM='0')
     root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, '-c', code, model_root], cwd=root_dir, env=env,
                        capture_output=True, text=True, timeout=300)
