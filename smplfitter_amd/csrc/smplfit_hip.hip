@@ -464,6 +464,7 @@ __global__ __launch_bounds__(64) void k_joint_stage(DevModel m, JointStageArgs a
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+template <bool TRANSPOSED>
 __global__ __launch_bounds__(256) void k_posedirs_gemm(const float* __restrict__ A,
                                                        const float* __restrict__ Bm,
                                                        const float* __restrict__ bias,
@@ -484,7 +485,8 @@ __global__ __launch_bounds__(256) void k_posedirs_gemm(const float* __restrict__
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = bv;
+      for (int r = 0; r < 16; ++r)  // transposed: the tile's rows are the columns n
+        acc[mi][ni][r] = TRANSPOSED ? bias[n0 + wn + ni * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk] : bv;
   }
   // global -> register staging: A 128x16 (2 float4 / thread), B 16x128 (2 float4 / thread)
   const int a_row = tid >> 2, a_kc = (tid & 3) * 4;
@@ -518,10 +520,17 @@ __global__ __launch_bounds__(256) void k_posedirs_gemm(const float* __restrict__
       const float a1 = As[buf][wm + 32 + l31][2 * kk + lk];
       const float b0 = Bs[buf][2 * kk + lk][wn + l31];
       const float b1 = Bs[buf][2 * kk + lk][wn + 32 + l31];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      if (TRANSPOSED) {  // operands swapped: instances become the columns of the result tile
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a0, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a1, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a1, acc[1][1], 0, 0, 0);
+      } else {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
     }
     if (it + 1 < nk) sstore(buf ^ 1);
     __syncthreads();
@@ -533,9 +542,15 @@ __global__ __launch_bounds__(256) void k_posedirs_gemm(const float* __restrict__
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        const int col = n0 + wn + ni * 32 + l31;
-        C[(size_t)row * N + col] = acc[mi][ni][r];
+        if (TRANSPOSED) {  // batch-major: [instance / 64][n][64]
+          const int inst = m0 + wm + mi * 32 + l31;
+          const int n = n0 + wn + ni * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          C[((size_t)(inst >> 6) * N + n) * 64 + (inst & 63)] = acc[mi][ni][r];
+        } else {
+          const int row = m0 + wm + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          const int col = n0 + wn + ni * 32 + l31;
+          C[(size_t)row * N + col] = acc[mi][ni][r];
+        }
       }
 }
 
@@ -1756,13 +1771,17 @@ bool use_pair_form() {
 }
 
 // Batch-major vertex kernels: the default whenever they apply (unit vertex weights, target joints
-// given, 10 betas, 4 skinning pairs per vertex, SMPL-sized GEMM); SMPLFIT_BM=0 selects the
+// given, 10 betas, 4 skinning pairs per vertex); SMPLFIT_BM=0 selects the
 // wave-per-instance kernels everywhere (they also serve every other configuration).
 bool use_bm() {
   const char* e = getenv("SMPLFIT_BM");
   return !(e && e[0] == '0');
 }
-bool bm_applies(const DevModel& d) { return use_bm() && d.Kp == 208 && d.KW == 4 && d.S == 10; }
+// Small vertex subsets stay on the wave-per-instance kernels: the pair-Gram and combine passes cost the
+// same per instance whatever V is (measured at V = 1024, B = 16384: 4.15 M fits/s batch-major vs 4.63 M).
+bool bm_applies(const DevModel& d) {
+  return use_bm() && d.KW == 4 && d.S == 10 && d.ngroups > 0 && d.V >= 2048;
+}
 
 template <int S, int KW>
 void launch_lbs_bm(const DevModel& d, const Workspace& ws, int B, hipStream_t st) {
@@ -1867,8 +1886,6 @@ int check_common(const smplfit_handle* h, int batch, void* workspace, size_t wor
 
 int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, bool transposed = false) {
   const int Mp = (int)align_up((size_t)B, 128), N = 3 * d.Vp;
-  if (transposed && d.Kp != 208)
-    return fail(SMPLFIT_ERR_UNSUPPORTED, "batch-major path: only the A-stationary GEMM (Kp == 208)");
   if (d.Kp == 208) {  // SMPL (J = 24): A-stationary kernel, 104 A registers per lane
     constexpr int NK2 = 104;
     const int ntiles = N / 32;
@@ -1886,8 +1903,12 @@ int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, b
                          ws.rp, d.pdSw, d.vtN, ws.vposed, N, per, Mp);
     return 0;
   }
-  hipLaunchKernelGGL(k_posedirs_gemm, dim3((N / 128) * (Mp / 128)), dim3(256), 0, st, ws.rp, d.pdT,
-                     d.vtN, ws.vposed, Mp, N, d.Kp);
+  if (transposed)
+    hipLaunchKernelGGL(k_posedirs_gemm<true>, dim3((N / 128) * (Mp / 128)), dim3(256), 0, st, ws.rp, d.pdT,
+                       d.vtN, ws.vpT, Mp, N, d.Kp);
+  else
+    hipLaunchKernelGGL(k_posedirs_gemm<false>, dim3((N / 128) * (Mp / 128)), dim3(256), 0, st, ws.rp, d.pdT,
+                       d.vtN, ws.vposed, Mp, N, d.Kp);
   return 0;
 }
 
