@@ -1254,7 +1254,7 @@ __host__ __device__ constexpr int brec_stride(int S, int KW) { return brec_d(S, 
 constexpr int kBW = 8;  // waves per workgroup of the batch-major kernels (they share the staged joints)
 
 template <int S, int KW>
-__global__ __launch_bounds__(64 * kBW) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lbs_partsum_bm(DevModel m, Workspace ws, int B, int Mp, int exp) {
+__global__ __launch_bounds__(64 * kBW) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lbs_partsum_bm(DevModel m, Workspace ws, int B, int Mp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int STRIDE = sf::jd_stride(S), BW = brec_w(S), BS = brec_stride(S, KW);
   static_assert(KW == 4, "batch-major kernels: 4 skinning pairs per vertex");
@@ -1303,8 +1303,7 @@ __global__ __launch_bounds__(64 * kBW) __attribute__((amdgpu_waves_per_eu(4, 4))
   // LDS, posed and accumulated.
   struct Raw { float x0, x1, x2, t0, t1, t2; };
   auto fetch = [&](int v) {
-    size_t o = (size_t)v * 64;
-    if (exp == 1 || exp == 5) o = (size_t)(v & 7) * 64;  // ablation: streams L2-hot
+    const size_t o = (size_t)v * 64;
     Raw r;
     r.x0 = vp[o]; r.x1 = vp[o + cstr]; r.x2 = vp[o + 2 * cstr];
     r.t0 = tp[o]; r.t1 = tp[o + cstr]; r.t2 = tp[o + 2 * cstr];
@@ -1314,7 +1313,7 @@ __global__ __launch_bounds__(64 * kBW) __attribute__((amdgpu_waves_per_eu(4, 4))
                   float (&wq)[4]) {
     t01 = mk2(r.t0, r.t1);
     t2 = r.t2;
-    const float* rec = m.brec + (size_t)((exp == 3 || exp == 5) ? v0 : v) * BS;  // wave-uniform -> scalar loads
+    const float* rec = m.brec + (size_t)v * BS;  // wave-uniform -> scalar loads
     f2 vz = mk2(r.x2, 0.f);
     f2 vx = mk2(r.x0, 0.f), vy = mk2(r.x1, 0.f);
 #pragma unroll
@@ -1353,7 +1352,6 @@ __global__ __launch_bounds__(64 * kBW) __attribute__((amdgpu_waves_per_eu(4, 4))
       f2 Q0 = mk2(0, 0), Q1 = Q0, Q2 = Q0, Q3 = Q0, Q4 = Q0, Q5 = Q0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if ((exp == 2 || exp == 5) && k > 0) break;  // ablation: one joint instead of four
         const float* src = smem + off[k];
         const float w = wq[k];
         Q0 += w * mk2(src[0], src[64]);
@@ -1381,7 +1379,6 @@ __global__ __launch_bounds__(64 * kBW) __attribute__((amdgpu_waves_per_eu(4, 4))
       sa2 += a2;
     };
     int v = v0;
-    if (exp == 4) v = v1;  // ablation: staging + combine only
     for (; v + 1 < v1; v += 2) {
       step(v, rB, rA);
       step(v + 1, rA, rB);
@@ -1788,8 +1785,7 @@ void launch_lbs_bm(const DevModel& d, const Workspace& ws, int B, hipStream_t st
   const int Mp = (int)align_up((size_t)B, 128);
   const size_t lds = (size_t)kGQ * 12 * 64 * 4;
   if constexpr (KW == 4)
-    hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4>), dim3(d.ngroups_used, Mp / 64), dim3(64 * kBW), lds, st, d, ws, B, Mp,
-                       getenv("SMPLFIT_EXP") ? atoi(getenv("SMPLFIT_EXP")) : 0);
+    hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4>), dim3(d.ngroups_used, Mp / 64), dim3(64 * kBW), lds, st, d, ws, B, Mp);
   hipLaunchKernelGGL(k_psum_combine, dim3((B + 255) / 256, d.J), dim3(256), 0, st, d, ws, B, Mp);
 }
 
