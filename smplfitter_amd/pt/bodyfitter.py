@@ -80,6 +80,35 @@ class BodyFitter(nn.Module):
         if initial_kid_factor is not None and not self.enable_kid:
             raise NotImplementedError(
                 'initial_kid_factor needs BodyFitter(enable_kid=True) on the HIP path')
+        # the reference defaults the kid ridge weight to beta_regularizer (pt/bodyfitter.py:1235-1237)
+        kid_reg = float(beta_regularizer if kid_regularizer is None else kid_regularizer)
+        if torch.compiler.is_compiling():  # one opaque operator for torch.compile / export
+            pose, betas, trans, kid, orient, rel = torch.ops.smplfitter_amd.fit(
+                self.body_model._model_id, self.enable_kid, target_vertices, target_joints,
+                vertex_weights, joint_weights, int(num_iter), float(beta_regularizer),
+                float(beta_regularizer2), kid_reg, bool(final_adjust_rots), initial_pose_rotvecs,
+                initial_shape_betas, initial_kid_factor)
+            result = dict(pose_rotvecs=pose, shape_betas=betas, trans=trans, orientations=orient,
+                          relative_orientations=rel)
+            if self.enable_kid:
+                result['kid_factor'] = kid
+        else:
+            result = self._fit_direct(target_vertices, target_joints, vertex_weights, joint_weights,
+                                      num_iter, beta_regularizer, beta_regularizer2, kid_reg,
+                                      final_adjust_rots, initial_pose_rotvecs, initial_shape_betas,
+                                      initial_kid_factor, _workspace)
+        # relative_orientations = parent^T @ global of the FINAL rotations (pt/bodyfitter.py:523-533);
+        # returned always (the reference returns the pre-refinement ones when neither
+        # 'relative_orientations' nor 'pose_rotvecs' is requested)
+        if 'pose_rotvecs' not in requested_keys:
+            result.pop('pose_rotvecs', None)
+        return result
+
+    def _fit_direct(self, target_vertices, target_joints, vertex_weights, joint_weights, num_iter,
+                    beta_regularizer, beta_regularizer2, kid_reg, final_adjust_rots,
+                    initial_pose_rotvecs, initial_shape_betas, initial_kid_factor, _workspace):
+        """The C-ABI call behind ``fit`` (and behind the ``smplfitter_amd::fit`` operator): every result
+        tensor, ``pose_rotvecs`` included."""
         bm = self.body_model
         device = bm.v_template.device
         for t in (target_vertices, target_joints, vertex_weights, joint_weights):
@@ -109,8 +138,6 @@ class BodyFitter(nn.Module):
         orient = torch.empty((B, J, 3, 3), dtype=torch.float32, device=device)
         rel = torch.empty((B, J, 3, 3), dtype=torch.float32, device=device)
         kid = torch.empty((B,), dtype=torch.float32, device=device) if self.enable_kid else None
-        # the reference defaults the kid ridge weight to beta_regularizer (pt/bodyfitter.py:1235-1237)
-        kid_reg = float(beta_regularizer if kid_regularizer is None else kid_regularizer)
         if B > 0:
             h = bm._native(device, kid=self.enable_kid)
             ws = _workspace if _workspace is not None else bm._workspace(h, B, device)
@@ -123,15 +150,12 @@ class BodyFitter(nn.Module):
                     0 if init_betas is None else init_betas.shape[1], _ptr(init_kid), _ptr(pose),
                     _ptr(betas), _ptr(trans), _ptr(kid), _ptr(orient), _ptr(rel), _ptr(ws), ws.numel(),
                     C.c_void_p(stream)))
-        # relative_orientations = parent^T @ global of the FINAL rotations (pt/bodyfitter.py:523-533);
-        # returned always (the reference returns the pre-refinement ones when neither
-        # 'relative_orientations' nor 'pose_rotvecs' is requested)
-        result = dict(shape_betas=betas, trans=trans, orientations=orient, relative_orientations=rel)
+        result = dict(pose_rotvecs=pose, shape_betas=betas, trans=trans, orientations=orient,
+                      relative_orientations=rel)
         if self.enable_kid:
             result['kid_factor'] = kid
-        if 'pose_rotvecs' in requested_keys:
-            result['pose_rotvecs'] = pose
         return result
+
 
     def fit_with_known_pose(
         self,

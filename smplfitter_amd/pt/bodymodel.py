@@ -66,6 +66,9 @@ class BodyModel(nn.Module):
         if self.vertex_subset is None:
             self.vertex_subset = np.arange(self.num_vertices)
         self._handles = {}  # device index -> _lib.Handle (model constants uploaded to that GPU)
+        from . import ops
+
+        ops.register_model(self)  # id for the torch.library operators (read while compiling)
         if device is not None:
             self.to(device)
 
@@ -112,6 +115,23 @@ class BodyModel(nn.Module):
         return_vertices: bool = True,
     ) -> dict[str, torch.Tensor]:
         """Vertices, joints and global orientations for a batch (pt/bodymodel.py:121-307)."""
+        if torch.compiler.is_compiling():  # one opaque operator for torch.compile / export
+            kid = kid_factor
+            if kid is not None and not isinstance(kid, torch.Tensor):
+                kid = torch.as_tensor(kid, dtype=torch.float32, device=self.v_template.device)
+            j, o, v = torch.ops.smplfitter_amd.forward(
+                self._model_id, pose_rotvecs, shape_betas, trans, kid, rel_rotmats, glob_rotmats,
+                return_vertices)
+            res = dict(joints=j, orientations=o)
+            if return_vertices:
+                res['vertices'] = v
+            return res
+        return self._forward_direct(pose_rotvecs, shape_betas, trans, kid_factor, rel_rotmats,
+                                    glob_rotmats, return_vertices)
+
+    def _forward_direct(self, pose_rotvecs=None, shape_betas=None, trans=None, kid_factor=None,
+                        rel_rotmats=None, glob_rotmats=None, return_vertices: bool = True):
+        """The C-ABI call behind ``forward`` (and behind the ``smplfitter_amd::forward`` operator)."""
         n_rot = sum(x is not None for x in (pose_rotvecs, rel_rotmats, glob_rotmats))
         if n_rot > 1:
             raise ValueError(

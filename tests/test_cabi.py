@@ -118,3 +118,23 @@ def test_flipper_host_tables(name, model_root, data_root, golden, monkeypatch):
     perm = BF.get_mirror_mapping(torch.from_numpy(rest)).numpy()
     assert (perm == ge['flip.mirror_inds_joints']).all()
     assert sorted(perm.tolist()) == list(range(md.num_joints))
+
+
+def test_torch_library_operators_registered(model_root):
+    """`smplfitter_amd::fit` / `::forward` exist with shape functions: under FakeTensorMode (what
+    torch.compile / export trace with) they return the result shapes without touching a GPU."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+
+    from smplfitter_amd.pt import BodyModel, ops
+
+    m = BodyModel('smpl', 'neutral', model_root=f'{model_root}/smpl', num_betas=10)
+    mid = ops.register_model(m)
+    assert ops.register_model(m) == mid
+    with FakeTensorMode():
+        tv = torch.empty((5, m.num_vertices, 3))
+        out = torch.ops.smplfitter_amd.fit(mid, False, tv, None, None, None, 3, 1.0, 0.0, 1.0, True, None,
+                                           None, None)
+        assert [tuple(t.shape) for t in out] == [(5, 72), (5, 10), (5, 3), (5,), (5, 24, 3, 3), (5, 24, 3, 3)]
+        fw = torch.ops.smplfitter_amd.forward(mid, torch.empty((5, 72)), None, None, None, None, None, True)
+        assert [tuple(t.shape) for t in fw] == [(5, 24, 3), (5, 24, 3, 3), (5, m.num_vertices, 3)]

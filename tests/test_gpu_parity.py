@@ -421,3 +421,23 @@ def test_body_flipper(name, model_root, data_root, golden, dev, monkeypatch):
         assert np.linalg.norm(va - vb, axis=-1).max() < 1e-4, tag
         assert np.abs(o['trans'] - ref['trans']).max() < 2e-5, tag
         assert np.abs(o['shape_betas'] - ref['shape_betas']).max() < 1e-3, tag
+
+
+def test_torch_compile_through_operators(model_root, golden, dev):
+    """Under torch.compile the fitter and the model are ONE opaque operator each
+    (smplfitter_amd::fit / ::forward, torch.library): full-graph capture, same numbers as eager."""
+    g = golden('smpl')
+    m, f = get_model(model_root, 'smpl', g, dev)
+    tv, tj = t(g['target_vertices'], dev), t(g['target_joints'], dev)
+
+    def pipeline(tv, tj):
+        r = f.fit(tv, tj, num_iter=3, beta_regularizer=1.0, requested_keys=['pose_rotvecs'])
+        back = m(r['pose_rotvecs'], r['shape_betas'], r['trans'])
+        return r['pose_rotvecs'], r['shape_betas'], r['trans'], back['vertices']
+
+    eager = pipeline(tv, tj)
+    compiled = torch.compile(pipeline, backend='aot_eager', fullgraph=True)(tv, tj)
+    for a, b in zip(eager, compiled):
+        assert torch.equal(a, b)
+    ref = {k: g[f'fit.it3_reg1_j_nw_fa.{k}'] for k in ('pose_rotvecs', 'shape_betas', 'trans')}
+    assert np.abs(compiled[2].cpu().numpy() - ref['trans']).max() < 1e-5
