@@ -151,6 +151,38 @@ int smplfit_fit_warm_f32(const smplfit_handle* h, const float* target_vertices,
                          float* relative_orientations, void* workspace, size_t workspace_bytes,
                          void* hip_stream);
 
+/* The general form of the fit call: every option of the two entry points above in one struct, plus
+ *   share_beta != 0 -- BodyFitter.fit(share_beta=True): one shape (betas [+ kid]) for the whole batch;
+ *   the regularised, centred normal equations of all instances are summed before the Cholesky solve
+ *   (pt/lstsq.py:24-26 through lstsq_partial_share :32-90 with every unknown shared), every instance
+ *   keeps its own translation.  The sum runs over the instances in order on one GPU; across GPUs it
+ *   would be one all-reduce of (S*S + S) doubles per shape solve (not wired: smplfitter_amd.dist raises).
+ * Zero-initialise the struct; fields left 0 / NULL mean "not given". */
+typedef struct smplfit_fit_args {
+  const float* target_vertices;      /* (B,V,3) */
+  const float* target_joints;        /* (B,J,3) or NULL */
+  const float* vertex_weights;       /* (B,V) or NULL */
+  const float* joint_weights;        /* (B,J) or NULL */
+  int32_t batch, num_iter;
+  float beta_regularizer, beta_regularizer2, kid_regularizer;
+  int32_t final_adjust_rots;
+  const float* initial_pose_rotvecs; /* (B,3J) or NULL */
+  const float* initial_shape_betas;  /* (B,num_initial_betas) or NULL */
+  int32_t num_initial_betas;
+  const float* initial_kid_factor;   /* (B) or NULL */
+  int32_t share_beta;
+  float* pose_rotvecs;               /* out (B,3J) */
+  float* shape_betas;                /* out (B,S) */
+  float* trans;                      /* out (B,3) */
+  float* kid_factor;                 /* out (B) or NULL */
+  float* orientations;               /* out (B,J,3,3) or NULL */
+  float* relative_orientations;      /* out (B,J,3,3) or NULL */
+  void* workspace;
+  size_t workspace_bytes;
+  void* hip_stream;
+} smplfit_fit_args;
+int smplfit_fit_ex_f32(const smplfit_handle* h, const smplfit_fit_args* args);
+
 /* BodyFitter.fit_with_known_shape (pt/bodyfitter.py:655-838): pose and translation (and, with
  * scale_fit, one scale factor per instance) for KNOWN shape parameters.  num_iter rotation passes
  * against the model posed at the current rotations, then fit_scale_and_translation (:1628-1681) and,

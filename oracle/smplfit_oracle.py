@@ -319,7 +319,8 @@ class OracleFitter:
         return R
 
     # -- shape solve (pt/bodyfitter.py:840-1102) --------------------------------------------------
-    def fit_shape(self, G, tv, tj, vw, jw, beta_reg, beta_reg2, kid_reg=None, reg_ref=None):
+    def fit_shape(self, G, tv, tj, vw, jw, beta_reg, beta_reg2, kid_reg=None, reg_ref=None,
+                  share_beta=False):
         """``reg_ref`` (B, S_all): values the ridge pulls towards (beta/kid_regularizer_reference,
         :1072-1081, :1224-1255); zeros when None."""
         m, dt, J, S, par = self.m, self.m.dtype, self.m.J, self.S_all, self.m.parents
@@ -381,7 +382,14 @@ class OracleFitter:
             lam = np.concatenate([lam, [float(beta_reg if kid_reg is None else kid_reg)]])
         if reg_ref is not None:
             rhs_c = rhs_c + (lam[None] * np.asarray(reg_ref, np.float64))[..., None]
-        x = np.linalg.solve(gram_c + np.diag(lam), rhs_c)  # SPD; reference uses Cholesky (:1083-1084)
+        if share_beta:
+            # one shape for the whole batch: the regularised normal equations of all instances are summed
+            # before the solve (pt/lstsq.py:24-26 via lstsq_partial_share :47-49; every instance keeps
+            # its own centring, hence its own translation)
+            Msum = (gram_c + np.diag(lam)[None]).sum(0)
+            x = np.broadcast_to(np.linalg.solve(Msum, rhs_c.sum(0))[None], rhs_c.shape).copy()
+        else:
+            x = np.linalg.solve(gram_c + np.diag(lam), rhs_c)  # SPD; reference uses Cholesky (:1083-1084)
         trans = (sb / Ws - (sA / Ws) @ x)[..., 0].astype(dt)
         beta = x[..., 0].astype(dt)
         joints = P[..., 0] + np.einsum('bjcs,bs->bjc', P[..., 1:], beta) + trans[:, None]
@@ -441,7 +449,7 @@ class OracleFitter:
     def fit(self, target_vertices, target_joints=None, vertex_weights=None, joint_weights=None,
             num_iter=1, beta_regularizer=1.0, beta_regularizer2=0.0, final_adjust_rots=True,
             return_stages=False, kid_regularizer=None, initial_pose_rotvecs=None,
-            initial_shape_betas=None, initial_kid_factor=None):
+            initial_shape_betas=None, initial_kid_factor=None, share_beta=False):
         m, dt, J, par = self.m, self.m.dtype, self.m.J, self.m.parents
         tv = np.asarray(target_vertices, dt)
         tj = None if target_joints is None else np.asarray(target_joints, dt)
@@ -474,14 +482,14 @@ class OracleFitter:
         stages['glob_rotmats_iter0'] = G.copy()
         for it in range(num_iter - 1):
             r = self.fit_shape(G, tv, tj, vw, jw, beta_regularizer, beta_regularizer2, kid_regularizer,
-                               reg_ref)
+                               reg_ref, share_beta)
             if it == 0:
                 stages['gram_cen0'], stages['rhs_cen0'] = r['gram_cen'], r['rhs_cen']
                 stages['shape_betas0'], stages['trans0'] = r['shape_betas'], r['trans']
             rj = r['joints'] if tj is not None else None
             G = self.fit_global_rotations(tv, tj, r['vertices'], rj, vw, jw) @ G
         r = self.fit_shape(G, tv, tj, vw, jw, beta_regularizer, beta_regularizer2, kid_regularizer,
-                           reg_ref)
+                           reg_ref, share_beta)
         if num_iter == 1:
             stages['gram_cen0'], stages['rhs_cen0'] = r['gram_cen'], r['rhs_cen']
             stages['shape_betas0'], stages['trans0'] = r['shape_betas'], r['trans']

@@ -33,11 +33,26 @@ EXPORTED_SYMBOLS = [
     'smplfit_create', 'smplfit_destroy', 'smplfit_last_error', 'smplfit_version',
     'smplfit_get_info', 'smplfit_get_table', 'smplfit_workspace_bytes', 'smplfit_fit_f32',
     'smplfit_forward_f32', 'smplfit_part_rotations_f32', 'smplfit_shape_solve_f32',
-    'smplfit_fit_known_shape_f32', 'smplfit_fit_warm_f32', 'smplfit_time_kernel_f32',
+    'smplfit_fit_known_shape_f32', 'smplfit_fit_warm_f32', 'smplfit_fit_ex_f32', 'smplfit_time_kernel_f32',
 ]  # fmt: skip
 
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)
+
+
+class FitArgs(C.Structure):
+    """smplfit_fit_args (include/smplfit.h)."""
+    _fields_ = [
+        ('target_vertices', C.c_void_p), ('target_joints', C.c_void_p), ('vertex_weights', C.c_void_p),
+        ('joint_weights', C.c_void_p), ('batch', C.c_int32), ('num_iter', C.c_int32),
+        ('beta_regularizer', C.c_float), ('beta_regularizer2', C.c_float), ('kid_regularizer', C.c_float),
+        ('final_adjust_rots', C.c_int32), ('initial_pose_rotvecs', C.c_void_p),
+        ('initial_shape_betas', C.c_void_p), ('num_initial_betas', C.c_int32),
+        ('initial_kid_factor', C.c_void_p), ('share_beta', C.c_int32), ('pose_rotvecs', C.c_void_p),
+        ('shape_betas', C.c_void_p), ('trans', C.c_void_p), ('kid_factor', C.c_void_p),
+        ('orientations', C.c_void_p), ('relative_orientations', C.c_void_p), ('workspace', C.c_void_p),
+        ('workspace_bytes', C.c_size_t), ('hip_stream', C.c_void_p),
+    ]
 
 
 class ModelDesc(C.Structure):
@@ -111,6 +126,8 @@ def load():
     lib.smplfit_fit_f32.restype = i32
     lib.smplfit_fit_warm_f32.argtypes = [vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.smplfit_fit_warm_f32.restype = i32
+    lib.smplfit_fit_ex_f32.argtypes = [vp, C.POINTER(FitArgs)]
+    lib.smplfit_fit_ex_f32.restype = i32
     lib.smplfit_forward_f32.argtypes = [vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, sz, vp]
     lib.smplfit_forward_f32.restype = i32
     lib.smplfit_part_rotations_f32.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, sz, vp]

@@ -306,13 +306,18 @@ SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
 //   _fit_shape_gram, bodyfitter.py:1054-1101.
 // gramv: NE+1 doubles (vertex block incl. W), gramj: NE+1 floats (joint block incl. W).
 // reg_ref (S) or null: values the ridge pulls towards (warm-started fit).
+// mode 0: solve this instance.  share_beta (pt/lstsq.py:24-26): mode 1 stops after the regularised,
+// centred system and writes it to cen[S*S + S] (lower triangle of M, then the right-hand side) for
+// the sum over the batch; mode 2 solves the summed system read from cen (shared by all instances)
+// and finishes with this instance's own translation.
 // Outputs: beta (S), trans (3), rjoints (J,3), jb (J,4) = T0 + T' beta (skinning translation).
 // ---------------------------------------------------------------------------------------------
 template <class Ctx>
 SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const double* gramv,
                        const float* gramj, const float* pext, const float* jd, const float* mb,
                        float beta_reg, float beta_reg2, float kid_reg, float* beta_out, float* trans_out,
-                       float* rjoints_out, float* jb_out, const float* reg_ref = nullptr) {
+                       float* rjoints_out, float* jb_out, const float* reg_ref = nullptr, int mode = 0,
+                       double* cen = nullptr) {
   const int J = tb.J, S = tb.S, S1 = S + 1;
   const int NG = ne_ng(S), NE = ne_size(S);
   double* sum = reinterpret_cast<double*>(scratch);  // NE+1   (scratch is 8-byte aligned)
@@ -354,6 +359,16 @@ SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const doubl
     x[i] = r;
   }
   cx.sync();
+  if (mode == 1) {
+    SF_FOR(k, S * S) cen[k] = (k % S <= k / S) ? M[k] : 0.0;
+    SF_FOR(i, S) cen[S * S + i] = x[i];
+    return;
+  }
+  if (mode == 2) {
+    SF_FOR(k, S * S) M[k] = cen[k];
+    SF_FOR(i, S) x[i] = cen[S * S + i];
+    cx.sync();
+  }
   // in-place Cholesky M = L L^T (:1083), column by column
   for (int k = 0; k < S; ++k) {
     if (cx.lane == 0) M[k * S + k] = sqrt(M[k * S + k]);

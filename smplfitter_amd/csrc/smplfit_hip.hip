@@ -138,6 +138,7 @@ struct Workspace {
   float* mbj;      // (B,J,3) per-joint residual moments (pair-Gram form)
   float* scale;    // (B) scale_corr of the known-shape fit
   float* regref;   // (B,S) ridge reference of the warm-started fit
+  double* cen;     // (B, S*S+S) centred regularised systems of a share_beta fit; row B = their sum
   // batch-major path: streams with the instance index innermost (lane = instance reads coalesce)
   float* vpT;      // (Mp/64, 3*Vp, 64) v_posed, written by the GEMM
   float* tT;       // (Mp/64, 3*Vp, 64) centred targets, transposed from tvs
@@ -180,6 +181,7 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w) {
   ws.mbj = (float*)take((size_t)B * J * 3 * 4);
   ws.scale = (float*)take((size_t)B * 4);
   ws.regref = (float*)take((size_t)B * S * 4);
+  ws.cen = (double*)take(((size_t)B + 1) * (S * S + S) * 8);
   ws.vpT = (float*)take(Mp * 3 * Vp * 4);
   ws.tT = (float*)take(Mp * 3 * Vp * 4);
   ws.psumP = (float*)take((size_t)t.groups.size() * 16 * Mp * 4);
@@ -897,9 +899,10 @@ __global__ __launch_bounds__(64) void k_pair_gram(DevModel m, Workspace ws) {
 // ------------------------------------------------------------------------------------------------
 // K4: solve.  grid B, block 64.
 // ------------------------------------------------------------------------------------------------
+// mode 0: per-instance solve; 1 / 2: the two halves of a share_beta solve (sf::solve_stage)
 __global__ __launch_bounds__(64) void k_shape_solve(DevModel m, Workspace ws, float beta_reg,
                                                     float beta_reg2, float kid_reg, int pair_form,
-                                                    int use_ref) {
+                                                    int use_ref, int mode = 0, int B = 0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, J = m.J, S = m.S;
   DevCtx cx{(int)threadIdx.x, 64};
@@ -908,7 +911,25 @@ __global__ __launch_bounds__(64) void k_shape_solve(DevModel m, Workspace ws, fl
                   ws.pext + (size_t)b * J * 3 * (S + 1), ws.jd + (size_t)b * J * sf::jd_stride(S),
                   pair_form ? ws.mbj + (size_t)b * J * 3 : nullptr, beta_reg, beta_reg2, kid_reg,
                   ws.beta + (size_t)b * S, ws.trans + (size_t)b * 3, ws.rjoints + (size_t)b * J * 3,
-                  ws.jb + (size_t)b * J * 4, use_ref ? ws.regref + (size_t)b * S : nullptr);
+                  ws.jb + (size_t)b * J * 4, use_ref ? ws.regref + (size_t)b * S : nullptr, mode,
+                  mode == 1 ? ws.cen + (size_t)b * (S * S + S) : ws.cen + (size_t)B * (S * S + S));
+}
+
+// share_beta: sum of the per-instance systems over the batch, instances in order (deterministic);
+// one workgroup, thread = entry of the (S*S + S) record; the sum lands in row B of ws.cen.
+__global__ __launch_bounds__(512) void k_share_reduce(Workspace ws, int B, int NC) {
+  const int e = threadIdx.x;
+  if (e >= NC) return;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int b = 0;
+  for (; b + 3 < B; b += 4) {
+    a0 += ws.cen[(size_t)b * NC + e];
+    a1 += ws.cen[(size_t)(b + 1) * NC + e];
+    a2 += ws.cen[(size_t)(b + 2) * NC + e];
+    a3 += ws.cen[(size_t)(b + 3) * NC + e];
+  }
+  for (; b < B; ++b) a0 += ws.cen[(size_t)b * NC + e];
+  ws.cen[(size_t)B * NC + e] = (a0 + a1) + (a2 + a3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1931,6 +1952,7 @@ struct FitOptions {
   const float* init_betas = nullptr;  // (B,init_nb) or null
   int init_nb = 0;
   const float* init_kid = nullptr;    // (B) or null
+  int share_beta = 0;                 // one shape for the whole batch (pt/lstsq.py:24-26)
 };
 
 int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const float* vw,
@@ -2020,8 +2042,18 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     }
     // K4 stays its own launch: fused into the prologue of the LBS kernel (template flag SOLVE) its
     // ~40 serial barriers stall all four waves of the workgroup and the kernel ran 230 us longer
-    hipLaunchKernelGGL(k_shape_solve, dim3(B), dim3(64), solve_lds(d), st, d, ws, o.beta_reg,
-                       o.beta_reg2, o.kid_reg, (bm || (!eff_v && use_pair_form())) ? 1 : 0, use_ref);
+    const int pair_in = (bm || (!eff_v && use_pair_form())) ? 1 : 0;
+    if (o.share_beta) {  // assemble per instance, sum over the batch, solve the sum + own translation
+      const int NC = d.S * d.S + d.S;
+      hipLaunchKernelGGL(k_shape_solve, dim3(B), dim3(64), solve_lds(d), st, d, ws, o.beta_reg,
+                         o.beta_reg2, o.kid_reg, pair_in, use_ref, 1, B);
+      hipLaunchKernelGGL(k_share_reduce, dim3(1), dim3(512), 0, st, ws, B, NC);
+      hipLaunchKernelGGL(k_shape_solve, dim3(B), dim3(64), solve_lds(d), st, d, ws, o.beta_reg,
+                         o.beta_reg2, o.kid_reg, pair_in, use_ref, 2, B);
+    } else {
+      hipLaunchKernelGGL(k_shape_solve, dim3(B), dim3(64), solve_lds(d), st, d, ws, o.beta_reg,
+                         o.beta_reg2, o.kid_reg, pair_in, use_ref);
+    }
     const bool last = it + 1 == o.num_iter;
     if (last && !o.final_adjust) break;  // nothing consumes the re-evaluated mesh
     if (bm) {
@@ -2413,6 +2445,35 @@ int smplfit_fit_warm_f32(const smplfit_handle* h, const float* target_vertices,
                          float* shape_betas, float* trans, float* kid_factor, float* orientations,
                          float* relative_orientations, void* workspace, size_t workspace_bytes,
                          void* hip_stream) {
+  smplfit_fit_args a{};
+  a.target_vertices = target_vertices; a.target_joints = target_joints;
+  a.vertex_weights = vertex_weights; a.joint_weights = joint_weights;
+  a.batch = batch; a.num_iter = num_iter;
+  a.beta_regularizer = beta_regularizer; a.beta_regularizer2 = beta_regularizer2;
+  a.kid_regularizer = kid_regularizer; a.final_adjust_rots = final_adjust_rots;
+  a.initial_pose_rotvecs = initial_pose_rotvecs; a.initial_shape_betas = initial_shape_betas;
+  a.num_initial_betas = num_initial_betas; a.initial_kid_factor = initial_kid_factor;
+  a.pose_rotvecs = pose_rotvecs; a.shape_betas = shape_betas; a.trans = trans; a.kid_factor = kid_factor;
+  a.orientations = orientations; a.relative_orientations = relative_orientations;
+  a.workspace = workspace; a.workspace_bytes = workspace_bytes; a.hip_stream = hip_stream;
+  return smplfit_fit_ex_f32(h, &a);
+}
+
+int smplfit_fit_ex_f32(const smplfit_handle* h, const smplfit_fit_args* args) {
+  if (!args) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_ex_f32: null arguments");
+  const float *target_vertices = args->target_vertices, *target_joints = args->target_joints,
+              *vertex_weights = args->vertex_weights, *joint_weights = args->joint_weights,
+              *initial_pose_rotvecs = args->initial_pose_rotvecs,
+              *initial_shape_betas = args->initial_shape_betas, *initial_kid_factor = args->initial_kid_factor;
+  const int batch = args->batch, num_iter = args->num_iter, final_adjust_rots = args->final_adjust_rots,
+            num_initial_betas = args->num_initial_betas;
+  const float beta_regularizer = args->beta_regularizer, beta_regularizer2 = args->beta_regularizer2,
+              kid_regularizer = args->kid_regularizer;
+  float *pose_rotvecs = args->pose_rotvecs, *shape_betas = args->shape_betas, *trans = args->trans,
+        *kid_factor = args->kid_factor, *orientations = args->orientations,
+        *relative_orientations = args->relative_orientations;
+  void *workspace = args->workspace, *hip_stream = args->hip_stream;
+  const size_t workspace_bytes = args->workspace_bytes;
   int rc = check_common(h, batch, workspace, workspace_bytes);
   if (rc) return rc;
   if (!target_vertices || !pose_rotvecs || !shape_betas || !trans)
@@ -2425,9 +2486,11 @@ int smplfit_fit_warm_f32(const smplfit_handle* h, const float* target_vertices,
   const int inb = initial_shape_betas ? num_initial_betas : 0;
   FitOptions o{num_iter, beta_regularizer, beta_regularizer2, kid_regularizer,
                final_adjust_rots ? 1 : 0, 0};
+  o.share_beta = args->share_beta ? 1 : 0;
   hipStream_t st = (hipStream_t)hip_stream;
   int sizes[kMaxChunks];
-  const int nchunk = h->have_streams ? chunk_plan(batch, sizes) : 1;
+  // share_beta couples all instances in every shape solve: one chunk
+  const int nchunk = (h->have_streams && !o.share_beta) ? chunk_plan(batch, sizes) : 1;
   const int J = h->t.J, V = h->t.V, Sb = h->t.S - h->t.n_kid;
   auto run_chunk = [&](int b0, int nb, char* wsbase, hipStream_t cs) -> int {
     Workspace ws;

@@ -57,6 +57,10 @@ def fit_sharded(fit_fn, target_vertices: torch.Tensor, target_joints: Optional[t
                 num_joints: int, num_betas: int, group=None, **fit_kwargs) -> dict:
     """Every rank holds the FULL ``(B, V, 3)`` inputs (or generates them); each fits its block with
     ``fit_fn`` (e.g. ``BodyFitter.fit``) and all ranks receive the full result dict."""
+    if fit_kwargs.get('share_beta'):
+        # the shared shape couples every instance of the batch in each solve: across ranks that is one
+        # all-reduce of the (S*S + S) summed systems per shape solve, inside the fit -- not wired
+        raise NotImplementedError('share_beta fits are not sharded: run them on one GPU')
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     total = target_vertices.shape[0]

@@ -38,7 +38,7 @@ class BodyFitter(nn.Module):
             raise ValueError('Only one of estim_scale_target and estim_scale_fit can be True')
         unsupported = []
         if share_beta:
-            unsupported.append('share_beta')
+            unsupported.append('share_beta (outside fit)')
         if scale_target or scale_fit:
             unsupported.append('scale_target/scale_fit')
         if beta_ref is not None or kid_ref is not None:
@@ -76,7 +76,7 @@ class BodyFitter(nn.Module):
         warm-start the fit (``smplfit_fit_warm_f32``; reference :363-382)."""
         if requested_keys is None:
             requested_keys = ['pose_rotvecs']
-        self._check_options(share_beta, scale_target, scale_fit)
+        self._check_options(False, scale_target, scale_fit)  # share_beta: smplfit_fit_ex_f32
         if initial_kid_factor is not None and not self.enable_kid:
             raise NotImplementedError(
                 'initial_kid_factor needs BodyFitter(enable_kid=True) on the HIP path')
@@ -87,7 +87,7 @@ class BodyFitter(nn.Module):
                 self.body_model._model_id, self.enable_kid, target_vertices, target_joints,
                 vertex_weights, joint_weights, int(num_iter), float(beta_regularizer),
                 float(beta_regularizer2), kid_reg, bool(final_adjust_rots), initial_pose_rotvecs,
-                initial_shape_betas, initial_kid_factor)
+                initial_shape_betas, initial_kid_factor, bool(share_beta))
             result = dict(pose_rotvecs=pose, shape_betas=betas, trans=trans, orientations=orient,
                           relative_orientations=rel)
             if self.enable_kid:
@@ -96,7 +96,7 @@ class BodyFitter(nn.Module):
             result = self._fit_direct(target_vertices, target_joints, vertex_weights, joint_weights,
                                       num_iter, beta_regularizer, beta_regularizer2, kid_reg,
                                       final_adjust_rots, initial_pose_rotvecs, initial_shape_betas,
-                                      initial_kid_factor, _workspace)
+                                      initial_kid_factor, _workspace, share_beta)
         # relative_orientations = parent^T @ global of the FINAL rotations (pt/bodyfitter.py:523-533);
         # returned always (the reference returns the pre-refinement ones when neither
         # 'relative_orientations' nor 'pose_rotvecs' is requested)
@@ -106,7 +106,8 @@ class BodyFitter(nn.Module):
 
     def _fit_direct(self, target_vertices, target_joints, vertex_weights, joint_weights, num_iter,
                     beta_regularizer, beta_regularizer2, kid_reg, final_adjust_rots,
-                    initial_pose_rotvecs, initial_shape_betas, initial_kid_factor, _workspace):
+                    initial_pose_rotvecs, initial_shape_betas, initial_kid_factor, _workspace,
+                    share_beta=False):
         """The C-ABI call behind ``fit`` (and behind the ``smplfitter_amd::fit`` operator): every result
         tensor, ``pose_rotvecs`` included."""
         bm = self.body_model
@@ -143,13 +144,22 @@ class BodyFitter(nn.Module):
             ws = _workspace if _workspace is not None else bm._workspace(h, B, device)
             with torch.cuda.device(device):
                 stream = torch.cuda.current_stream(device).cuda_stream
-                _lib.check(_lib.load().smplfit_fit_warm_f32(
-                    h.ptr, _ptr(tv), _ptr(tj), _ptr(vw), _ptr(jw), B, int(num_iter),
-                    float(beta_regularizer), float(beta_regularizer2), kid_reg,
-                    int(bool(final_adjust_rots)), _ptr(init_pose), _ptr(init_betas),
-                    0 if init_betas is None else init_betas.shape[1], _ptr(init_kid), _ptr(pose),
-                    _ptr(betas), _ptr(trans), _ptr(kid), _ptr(orient), _ptr(rel), _ptr(ws), ws.numel(),
-                    C.c_void_p(stream)))
+                args = _lib.FitArgs(
+                    target_vertices=tv.data_ptr(), target_joints=tj.data_ptr() if tj is not None else None,
+                    vertex_weights=vw.data_ptr() if vw is not None else None,
+                    joint_weights=jw.data_ptr() if jw is not None else None, batch=B, num_iter=int(num_iter),
+                    beta_regularizer=float(beta_regularizer), beta_regularizer2=float(beta_regularizer2),
+                    kid_regularizer=kid_reg, final_adjust_rots=int(bool(final_adjust_rots)),
+                    initial_pose_rotvecs=init_pose.data_ptr() if init_pose is not None else None,
+                    initial_shape_betas=init_betas.data_ptr() if init_betas is not None else None,
+                    num_initial_betas=0 if init_betas is None else init_betas.shape[1],
+                    initial_kid_factor=init_kid.data_ptr() if init_kid is not None else None,
+                    share_beta=int(bool(share_beta)), pose_rotvecs=pose.data_ptr(),
+                    shape_betas=betas.data_ptr(), trans=trans.data_ptr(),
+                    kid_factor=kid.data_ptr() if kid is not None else None, orientations=orient.data_ptr(),
+                    relative_orientations=rel.data_ptr(), workspace=ws.data_ptr(),
+                    workspace_bytes=ws.numel(), hip_stream=stream)
+                _lib.check(_lib.load().smplfit_fit_ex_f32(h.ptr, C.byref(args)))
         result = dict(pose_rotvecs=pose, shape_betas=betas, trans=trans, orientations=orient,
                       relative_orientations=rel)
         if self.enable_kid:

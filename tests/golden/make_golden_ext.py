@@ -11,6 +11,8 @@ share targets; only outputs are stored here:
   (pt/bodyfitter.py:1628-1681);
 * ``warm.<case>.*`` for ``fit`` with ``initial_pose_rotvecs / initial_shape_betas / initial_kid_factor``
   (:363-382), including BodyFlipper's configuration (pt/bodyflipper.py:71-81);
+* ``share.<case>.*`` for ``fit(share_beta=True)`` (pt/lstsq.py) on a batch of one shape in several
+  poses (targets rebuilt by the tests with the repo's numpy forward; ``target_vertices_sub`` pins them);
 * ``flip.*`` for ``BodyFlipper`` (mirror joint permutation, ``flip_vertices`` sampled every 50th vertex,
   ``naive_flip_rotvecs``, ``flip`` results) on the synthetic mirror / transfer files.
 
@@ -33,8 +35,8 @@ from smplfitter.pt.bodyfitter import fit_scale_and_translation  # noqa: E402
 from smplfitter_amd import synth  # noqa: E402
 
 sys.path.insert(0, osp.join(HERE, '..'))
-from util import (KNOWN_SHAPE_CASES, SCALE_TRANS_CASES, WARM_CASES, known_shape_inputs,  # noqa: E402
-                  scale_trans_inputs, warm_inputs)
+from util import (KNOWN_SHAPE_CASES, SCALE_TRANS_CASES, SHARE_CASES, WARM_CASES,  # noqa: E402
+                  known_shape_inputs, load_md, make_oracle, scale_trans_inputs, share_inputs, warm_inputs)
 
 def main():
     torch.set_num_threads(8)
@@ -76,6 +78,20 @@ def main():
                 for k in ('pose_rotvecs', 'shape_betas', 'trans', 'kid_factor', 'orientations'):
                     if k in r:
                         out[f'warm.{case}.{k}'] = r[k].numpy()
+            # share_beta: the targets come from the repo's own numpy forward (pinned by golden_<kind>.npz)
+            _, md_ = load_md(root, kind, g)
+            om_, _ = make_oracle(md_, kind)
+            for case in SHARE_CASES:
+                if kind != 'smpl' and case != 'a':
+                    continue
+                kid_fit, tv, kw = share_inputs(g, om_, case)
+                out[f'share.{case}.target_vertices_sub'] = tv[:, ::300]
+                kwt = {k: (T(v) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+                r = (kfitter if kid_fit else fitter).fit(
+                    T(tv), share_beta=True, requested_keys=['pose_rotvecs', 'shape_betas', 'trans'], **kwt)
+                for k in ('pose_rotvecs', 'shape_betas', 'trans', 'kid_factor', 'orientations'):
+                    if k in r:
+                        out[f'share.{case}.{k}'] = r[k].numpy()
             # BodyFlipper (pt/bodyflipper.py) on the synthetic mirror / transfer files of
             # synth.write_transfer_files
             os.environ['DATA_ROOT'] = synth.write_transfer_files(

@@ -224,16 +224,33 @@ struct Emu {
     }
   }
 
+  bool share_beta = false;  // one shape for the batch: assemble, sum in instance order, solve the sum
   void k4(float reg, float reg2, float kid_reg) {
-    const int J = t.J, NE1 = sf::ne_size(S) + 1;
+    const int J = t.J, NE1 = sf::ne_size(S) + 1, NC = S * S + S;
     HostCtx cx;
-    for (int b = 0; b < B; ++b)
+    std::vector<double> cen((size_t)(B + 1) * NC, 0.0);
+    auto stage = [&](int b, int mode, double* c) {
       sf::solve_stage(cx, jt, solve_base(), gramv.data() + (size_t)b * NE1, gramj.data() + (size_t)b * NE1,
                       pext.data() + (size_t)b * J * 3 * (S + 1), jd_b(b),
                       use_pair_gram ? mbj.data() + (size_t)b * J * 3 : nullptr, reg, reg2, kid_reg,
                       beta.data() + (size_t)b * S, trans.data() + (size_t)b * 3,
                       rjoints.data() + (size_t)b * J * 3, jb.data() + (size_t)b * J * 4,
-                      regref.empty() ? nullptr : regref.data() + (size_t)b * S);
+                      regref.empty() ? nullptr : regref.data() + (size_t)b * S, mode, c);
+    };
+    if (!share_beta) {
+      for (int b = 0; b < B; ++b) stage(b, 0, nullptr);
+      return;
+    }
+    for (int b = 0; b < B; ++b) stage(b, 1, cen.data() + (size_t)b * NC);
+    for (int e = 0; e < NC; ++e) {  // the summation order of k_share_reduce
+      double a[4] = {0, 0, 0, 0};
+      int b = 0;
+      for (; b + 3 < B; b += 4)
+        for (int q = 0; q < 4; ++q) a[q] += cen[(size_t)(b + q) * NC + e];
+      for (; b < B; ++b) a[0] += cen[(size_t)b * NC + e];
+      cen[(size_t)B * NC + e] = (a[0] + a[1]) + (a[2] + a[3]);
+    }
+    for (int b = 0; b < B; ++b) stage(b, 2, cen.data() + (size_t)B * NC);
   }
 
   void vertex(int b, int i, const float* be, int nb, const float* tr, float* v) {
@@ -274,6 +291,7 @@ struct Warm {  // warm start of fit (mirrors FitOptions::init_* in smplfit_hip.h
   const float* betas = nullptr;
   int nb = 0;
   const float* kid = nullptr;
+  int share_beta = 0;
 };
 thread_local Warm g_warm;  // set by hostemu_fit_warm around hostemu_fit
 
@@ -283,6 +301,7 @@ int fit_impl(const sf::HostTables& t, const float* tv, const float* tj, const fl
              float* pose, float* betas, float* trans, float* kid, float* orient, float* G0_out) {
   const Warm w = g_warm;
   Emu<S, KW> e(t, B);
+  e.share_beta = g_warm.share_beta != 0;
   const bool joints = tj != nullptr;
   const bool eff_v = joints ? (vw && jw) : (vw != nullptr);
   const bool eff_j = joints && vw && jw;
@@ -486,8 +505,9 @@ int hostemu_fit(const smplfit_model_desc* d, const float* tv, const float* tj, c
 int hostemu_fit_warm(const smplfit_model_desc* d, const float* tv, const float* tj, const float* vw,
                      const float* jw, int B, int num_iter, float reg, float reg2, float kid_reg,
                      int final_adjust, const float* init_pose, const float* init_betas, int init_nb,
-                     const float* init_kid, float* pose, float* betas, float* trans, float* kid,
-                     float* orient) {
+                     const float* init_kid, int share_beta, float* pose, float* betas, float* trans,
+                     float* kid, float* orient) {
+  g_warm.share_beta = share_beta;
   g_warm.pose = init_pose;
   g_warm.betas = init_betas;
   g_warm.nb = init_betas ? init_nb : 0;

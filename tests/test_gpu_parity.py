@@ -160,7 +160,9 @@ def test_edge_batches(model_root, golden, dev):
     with pytest.raises(ValueError):
         f.fit(tv, tj, scale_target=True, scale_fit=True)
     with pytest.raises(NotImplementedError):
-        f.fit(tv, tj, share_beta=True)
+        f.fit(tv, tj, scale_fit=True)
+    with pytest.raises(NotImplementedError):
+        f.fit_with_known_pose(torch.zeros(37, 72, device=dev), tv, tj, share_beta=True)
     with pytest.raises(ValueError):
         m(pose_rotvecs=torch.zeros(1, 72, device=dev), glob_rotmats=torch.zeros(1, 24, 3, 3, device=dev))
     with pytest.raises(TypeError):
@@ -441,3 +443,33 @@ def test_torch_compile_through_operators(model_root, golden, dev):
         assert torch.equal(a, b)
     ref = {k: g[f'fit.it3_reg1_j_nw_fa.{k}'] for k in ('pose_rotvecs', 'shape_betas', 'trans')}
     assert np.abs(compiled[2].cpu().numpy() - ref['trans']).max() < 1e-5
+
+
+@pytest.mark.parametrize('name', ['smpl', 'smplx'])
+def test_share_beta_goldens(name, model_root, golden, dev, vertex_path):
+    """fit(share_beta=True) (smplfit_fit_ex_f32) against the reference's fixture, both vertex paths."""
+    from smplfitter_amd.pt import BodyFitter
+
+    g, ge = golden(name), golden(f'ext_{name}')
+    kind, md = util.load_md(model_root, name, g)
+    om, _ = util.make_oracle(md, kind)
+    m, f = get_model(model_root, name, g, dev)
+    kf = BodyFitter(m, enable_kid=True)
+    for case in util.SHARE_CASES:
+        if f'share.{case}.trans' not in ge:
+            continue
+        kid_fit, tv, kw = util.share_inputs(g, om, case)
+        kwt = {k: (t(v, dev) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+        o = to_np((kf if kid_fit else f).fit(t(tv, dev), share_beta=True, requested_keys=['pose_rotvecs'], **kwt))
+        util.check_share(om, name, case, o, ge, kid_fit)
+    # a large batch takes the same (unchunked) path: all rows of shape_betas identical
+    B = 1500
+    rs = np.random.RandomState(8)
+    J = md.num_joints
+    fw = m(t((rs.randn(B, 3 * J) * 0.1).astype(np.float32), dev),
+           t(np.repeat((rs.randn(1, 10) * 0.5).astype(np.float32), B, 0), dev),
+           t(rs.randn(B, 3).astype(np.float32), dev))
+    r = f.fit(fw['vertices'], fw['joints'], num_iter=3, beta_regularizer=0.0, share_beta=True)
+    assert (r['shape_betas'] - r['shape_betas'][:1]).abs().max().item() == 0
+    back = m(r['pose_rotvecs'], r['shape_betas'], r['trans'])
+    assert (back['vertices'] - fw['vertices']).norm(dim=-1).mean().item() < 5e-3

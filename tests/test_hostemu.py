@@ -133,3 +133,17 @@ def test_warm_start_goldens(name, model_root, golden):
         kid_fit, tv, kw = util.warm_inputs(g, case)
         o = H.fit_warm(md, kind, tv, enable_kid=kid_fit, **kw)
         util.check_warm(om, name, case, o, ge, kid_fit)
+
+
+@pytest.mark.parametrize('name', ['smpl', 'smplx'])
+def test_share_beta_goldens(name, model_root, golden):
+    """share_beta through the shared solve stage (assemble / sum / solve the sum) against the reference."""
+    g, ge = golden(name), golden(f'ext_{name}')
+    kind, md = util.load_md(model_root, name, g)
+    om, _ = util.make_oracle(md, kind)
+    for case in util.SHARE_CASES:
+        if f'share.{case}.trans' not in ge:
+            continue
+        kid_fit, tv, kw = util.share_inputs(g, om, case)
+        o = H.fit_warm(md, kind, tv, enable_kid=kid_fit, share_beta=True, **kw)
+        util.check_share(om, name, case, o, ge, kid_fit)

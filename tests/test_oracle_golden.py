@@ -193,3 +193,22 @@ def test_warm_start_goldens(name, model_root, golden):
         tj = kw.pop('target_joints')
         o = (kf if kid_fit else of).fit(tv, tj, **kw)
         util.check_warm(om, name, case, o, ge, kid_fit)
+
+
+@pytest.mark.parametrize('name', ['smpl', 'smplx'])
+def test_share_beta_goldens(name, model_root, golden):
+    """fit(share_beta=True): the regularised normal equations of all instances are summed before the
+    solve (pt/lstsq.py:24-26), every instance keeps its own translation."""
+    g, ge = golden(name), golden(f'ext_{name}')
+    kind, md = util.load_md(model_root, name, g)
+    om, of = util.make_oracle(md, kind)
+    kf = O.OracleFitter(om, enable_kid=True)
+    for case in util.SHARE_CASES:
+        if f'share.{case}.trans' not in ge:
+            continue
+        kid_fit, tv, kw = util.share_inputs(g, om, case)
+        assert np.abs(tv[:, ::300] - ge[f'share.{case}.target_vertices_sub']).max() < 1e-6
+        kw = dict(kw)
+        tj = kw.pop('target_joints')
+        o = (kf if kid_fit else of).fit(tv, tj, share_beta=True, **kw)
+        util.check_share(om, name, case, o, ge, kid_fit)

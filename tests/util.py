@@ -145,3 +145,43 @@ def check_warm(om, name, case, o, ge, kid_fit):
     assert np.abs(o['shape_betas'] - ref['shape_betas']).max() < (3e-4 if name == 'smpl' else 1e-3), case
     if kid_fit:
         assert np.abs(o['kid_factor'] - ref['kid_factor']).max() < 1e-3, case
+
+
+# share_beta fits (one shape for the whole batch; reference pt/lstsq.py:24-26, :32-90)
+# case -> (enable_kid, joints, weights, fit kwargs)
+SHARE_CASES = {
+    'a': (False, True, False, dict(num_iter=3, beta_regularizer=1.0)),
+    'b': (False, False, True, dict(num_iter=2, beta_regularizer=0.5)),
+    'c': (True, True, False, dict(num_iter=2, beta_regularizer=1.0, kid_regularizer=2.0)),
+}
+
+
+def share_inputs(g, om, case):
+    """A batch of ONE body shape in different poses (+3 mm noise), built from the fixture's pose rows."""
+    kid_fit, joints, weights, kw = SHARE_CASES[case]
+    rs = np.random.RandomState(77)
+    B = g['pose'].shape[0]
+    betas = np.repeat(g['betas'][:1], B, 0)
+    fw = om.forward(g['pose'], betas, g['trans'])
+    tv = (fw['vertices'] + rs.randn(*fw['vertices'].shape) * 0.003).astype(np.float32)
+    kw = dict(kw)
+    kw['target_joints'] = fw['joints'].astype(np.float32) if joints else None
+    kw['vertex_weights'] = g['vertex_weights'] if weights else None
+    kw['joint_weights'] = g['joint_weights'] if (weights and joints) else None
+    return kid_fit, tv, kw
+
+
+def check_share(om, name, case, o, ge, kid_fit):
+    """share_beta fit against the reference's fixture.  The shared-shape pipeline amplifies fp32
+    reduction noise (the reference documents ~2e-3 in pose_rotvecs at the ankles, pt/bodyfitter.py
+    :250-255), so the mesh gate is 5e-4 m here and the shared shape itself is pinned tightly."""
+    keys = ('pose_rotvecs', 'shape_betas', 'trans') + (('kid_factor',) if kid_fit else ())
+    ref = {k: ge[f'share.{case}.{k}'] for k in keys}
+    assert np.abs(o['shape_betas'] - o['shape_betas'][:1]).max() == 0, case  # one shape for the batch
+    assert np.abs(o['shape_betas'] - ref['shape_betas']).max() < (1e-3 if name == 'smpl' else 3e-3), case
+    assert np.abs(o['trans'] - ref['trans']).max() < 1e-4, case
+    kw_o = dict(kid_factor=o['kid_factor']) if kid_fit else {}
+    kw_r = dict(kid_factor=ref['kid_factor']) if kid_fit else {}
+    va = om.forward(o['pose_rotvecs'], o['shape_betas'], o['trans'], **kw_o)['vertices']
+    vb = om.forward(ref['pose_rotvecs'], ref['shape_betas'], ref['trans'], **kw_r)['vertices']
+    assert np.linalg.norm(va - vb, axis=-1).max() < 5e-4, case
