@@ -37,3 +37,35 @@ run('C2 smpl', 'smpl', 4096)
 run('C3 smplx', 'smplx', 4096)
 run('C4 smpl-1024', 'smpl', 16384, subset=1024)
 run('plumbing smpl B=32', 'smpl', 32)
+
+
+def run_graphed(B=32, steps=200):
+    """Small batches are launch-bound (21+ kernels per fit): the same call captured into a HIP graph."""
+    m = BodyModel('smpl', 'neutral', model_root=f'{root}/smpl', num_betas=10, device=dev)
+    f = BodyFitter(m)
+    rs = np.random.RandomState(42)
+    t = lambda a: torch.from_numpy(a.astype(np.float32)).to(dev)
+    fw = m(t(rs.randn(B, 72) * 0.1), t(rs.randn(B, 10) * 0.5), t(rs.randn(B, 3)))
+    tv, tj = fw['vertices'].clone(), fw['joints'].clone()
+    ws = torch.empty(m._native(dev).workspace_bytes(B), dtype=torch.uint8, device=dev)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        f.fit(tv, tj, num_iter=3, _workspace=ws)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        f.fit(tv, tj, num_iter=3, _workspace=ws)
+    for _ in range(5):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    print(f'hipGraph replay smpl B={B}: {dt*1e3:.3f} ms/step, {B/dt:,.0f} fits/s', flush=True)
+
+
+run_graphed(32)
+run_graphed(256)
