@@ -320,7 +320,7 @@ class OracleFitter:
 
     # -- shape solve (pt/bodyfitter.py:840-1102) --------------------------------------------------
     def fit_shape(self, G, tv, tj, vw, jw, beta_reg, beta_reg2, kid_reg=None, reg_ref=None,
-                  share_beta=False):
+                  share_beta=False, scale_mode=0, scale_reg=0.0):
         """``reg_ref`` (B, S_all): values the ridge pulls towards (beta/kid_regularizer_reference,
         :1072-1081, :1224-1255); zeros when None."""
         m, dt, J, S, par = self.m, self.m.dtype, self.m.J, self.S_all, self.m.parents
@@ -369,9 +369,17 @@ class OracleFitter:
             sb = wb.sum(1)[..., None]  # (B,3,1)
             return tuple(x.astype(np.float64) for x in (gram, rhs, sA, sb)) + (W,)
 
-        gram, rhs, sA, sb, W = block(jac, b, evw)
+        jac_s, Pj = jac, P[..., 1:]
+        if scale_mode:  # the scale column of the design matrix (:1170-1175)
+            cv = -tv if scale_mode == 1 else pos
+            jac_s = np.concatenate([jac, cv[..., None]], -1)
+            if tj is not None:
+                cj = -tj if scale_mode == 1 else P[..., 0]
+                Pj = np.concatenate([P[..., 1:], cj[..., None]], -1)
+            S = S + 1
+        gram, rhs, sA, sb, W = block(jac_s, b, evw)
         if tj is not None:
-            g2, r2, sA2, sb2, W2 = block(P[..., 1:], tj - P[..., 0], ejw)
+            g2, r2, sA2, sb2, W2 = block(Pj, tj - P[..., 0], ejw)
             gram, rhs, sA, sb, W = gram + g2, rhs + r2, sA + sA2, sb + sb2, W + W2
         Ws = np.where(W == 0, 1.0, W)
         gram_c = gram - np.swapaxes(sA, 1, 2) @ sA / Ws
@@ -380,6 +388,10 @@ class OracleFitter:
         lam = np.concatenate([np.full(2, float(beta_reg2)), np.full(n_plain - 2, float(beta_reg))])
         if self.enable_kid:  # kid_regularizer defaults to beta_regularizer (pt/bodyfitter.py:1235-1242)
             lam = np.concatenate([lam, [float(beta_reg if kid_reg is None else kid_reg)]])
+        if scale_mode:
+            lam = np.concatenate([lam, [float(scale_reg)]])
+            if reg_ref is not None:
+                reg_ref = np.concatenate([np.asarray(reg_ref, np.float64), np.zeros((B, 1))], 1)
         if reg_ref is not None:
             rhs_c = rhs_c + (lam[None] * np.asarray(reg_ref, np.float64))[..., None]
         if share_beta:
@@ -392,10 +404,21 @@ class OracleFitter:
             x = np.linalg.solve(gram_c + np.diag(lam), rhs_c)  # SPD; reference uses Cholesky (:1083-1084)
         trans = (sb / Ws - (sA / Ws) @ x)[..., 0].astype(dt)
         beta = x[..., 0].astype(dt)
-        joints = P[..., 0] + np.einsum('bjcs,bs->bjc', P[..., 1:], beta) + trans[:, None]
-        verts = pos + np.einsum('bvcs,bs->bvc', jac, beta) + trans[:, None]
+        scale_corr = None
+        beta_eval = beta
+        if scale_mode:
+            scale_corr = (beta[:, -1] + 1).astype(dt)
+            beta = beta[:, :-1]
+            # scale_fit: the mesh is evaluated at shape / scale (:1289-1293) while the RETURNED
+            # shape_betas / kid_factor (and what the refinement is handed) stay undivided — the result
+            # dict is filled before the division (:1277-1283)
+            beta_eval = (beta / scale_corr[:, None]).astype(dt) if scale_mode == 2 else beta
+        joints = P[..., 0] + np.einsum('bjcs,bs->bjc', P[..., 1:], beta_eval) + trans[:, None]
+        verts = pos + np.einsum('bvcs,bs->bvc', jac, beta_eval) + trans[:, None]
         out = dict(shape_betas=beta[:, :n_plain], trans=trans, joints=joints.astype(dt),
                    vertices=verts.astype(dt), gram_cen=gram_c, rhs_cen=rhs_c, beta_all=beta)
+        if scale_corr is not None:
+            out['scale_corr'] = scale_corr
         if self.enable_kid:
             out['kid_factor'] = beta[:, n_plain]
         return out
@@ -449,7 +472,8 @@ class OracleFitter:
     def fit(self, target_vertices, target_joints=None, vertex_weights=None, joint_weights=None,
             num_iter=1, beta_regularizer=1.0, beta_regularizer2=0.0, final_adjust_rots=True,
             return_stages=False, kid_regularizer=None, initial_pose_rotvecs=None,
-            initial_shape_betas=None, initial_kid_factor=None, share_beta=False):
+            initial_shape_betas=None, initial_kid_factor=None, share_beta=False, scale_target=False,
+            scale_fit=False, scale_regularizer=0.0):
         m, dt, J, par = self.m, self.m.dtype, self.m.J, self.m.parents
         tv = np.asarray(target_vertices, dt)
         tj = None if target_joints is None else np.asarray(target_joints, dt)
@@ -488,26 +512,43 @@ class OracleFitter:
                 stages['shape_betas0'], stages['trans0'] = r['shape_betas'], r['trans']
             rj = r['joints'] if tj is not None else None
             G = self.fit_global_rotations(tv, tj, r['vertices'], rj, vw, jw) @ G
+        scale_mode = 1 if scale_target else 2 if scale_fit else 0  # only the LAST solve (:434-455)
         r = self.fit_shape(G, tv, tj, vw, jw, beta_regularizer, beta_regularizer2, kid_regularizer,
-                           reg_ref, share_beta)
+                           reg_ref, share_beta, scale_mode, scale_regularizer)
         if num_iter == 1:
             stages['gram_cen0'], stages['rhs_cen0'] = r['gram_cen'], r['rhs_cen']
             stages['shape_betas0'], stages['trans0'] = r['shape_betas'], r['trans']
-        if final_adjust_rots:
-            G = self.fit_global_rotations_dependent(
-                tv, tj, r['vertices'], r['joints'], vw, jw, G, r['beta_all'], r['trans']
-            )
+        sc = r.get('scale_corr')
+        if final_adjust_rots:  # (:462-511)
+            if scale_target:
+                s3 = sc[:, None, None]
+                G = self.fit_global_rotations_dependent(
+                    tv * s3, None if tj is None else tj * s3, r['vertices'], r['joints'], vw, jw, G,
+                    r['beta_all'], r['trans'])
+            elif scale_fit:
+                s3 = sc[:, None, None]
+                shift = (1 - s3) * r['trans'][:, None]
+                G = self.fit_global_rotations_dependent(
+                    tv, tj, (s3 * r['vertices'] + shift).astype(dt), (s3 * r['joints'] + shift).astype(dt),
+                    vw, jw, G, r['beta_all'], r['trans'], scale_corr=s3)
+            else:
+                G = self.fit_global_rotations_dependent(
+                    tv, tj, r['vertices'], r['joints'], vw, jw, G, r['beta_all'], r['trans']
+                )
         Gpar = np.concatenate([np.broadcast_to(np.eye(3, dtype=dt), (B, 1, 3, 3)), G[:, par[1:]]], 1)
         rel = np.swapaxes(Gpar, -1, -2) @ G
+        mean_out = mean * sc[:, None] if scale_target else mean / sc[:, None] if scale_fit else mean  # (:513-519)
         out = dict(
             pose_rotvecs=mat2rotvec(rel).reshape(B, J * 3),
             shape_betas=r['shape_betas'],
-            trans=(r['trans'] + mean).astype(dt),
+            trans=(r['trans'] + mean_out).astype(dt),
             orientations=G,
             relative_orientations=rel,
         )
         if self.enable_kid:
             out['kid_factor'] = r['kid_factor']
+        if sc is not None:
+            out['scale_corr'] = sc
         if return_stages:
             out['stages'] = stages
         return out

@@ -11,6 +11,7 @@ share targets; only outputs are stored here:
   (pt/bodyfitter.py:1628-1681);
 * ``warm.<case>.*`` for ``fit`` with ``initial_pose_rotvecs / initial_shape_betas / initial_kid_factor``
   (:363-382), including BodyFlipper's configuration (pt/bodyflipper.py:71-81);
+* ``scale.<case>.*`` for ``fit(scale_target=True)`` / ``fit(scale_fit=True)`` (:1170-1175, :434-519);
 * ``share.<case>.*`` for ``fit(share_beta=True)`` (pt/lstsq.py) on a batch of one shape in several
   poses (targets rebuilt by the tests with the repo's numpy forward; ``target_vertices_sub`` pins them);
 * ``flip.*`` for ``BodyFlipper`` (mirror joint permutation, ``flip_vertices`` sampled every 50th vertex,
@@ -35,8 +36,9 @@ from smplfitter.pt.bodyfitter import fit_scale_and_translation  # noqa: E402
 from smplfitter_amd import synth  # noqa: E402
 
 sys.path.insert(0, osp.join(HERE, '..'))
-from util import (KNOWN_SHAPE_CASES, SCALE_TRANS_CASES, SHARE_CASES, WARM_CASES,  # noqa: E402
-                  known_shape_inputs, load_md, make_oracle, scale_trans_inputs, share_inputs, warm_inputs)
+from util import (KNOWN_SHAPE_CASES, SCALE_CASES, SCALE_TRANS_CASES, SHARE_CASES, WARM_CASES,  # noqa: E402
+                  known_shape_inputs, load_md, make_oracle, scale_inputs, scale_trans_inputs, share_inputs,
+                  warm_inputs)
 
 def main():
     torch.set_num_threads(8)
@@ -78,6 +80,16 @@ def main():
                 for k in ('pose_rotvecs', 'shape_betas', 'trans', 'kid_factor', 'orientations'):
                     if k in r:
                         out[f'warm.{case}.{k}'] = r[k].numpy()
+            for case in SCALE_CASES:  # the scale unknown of the last shape solve
+                if kind != 'smpl' and case not in ('a', 'b'):
+                    continue
+                kid_fit, tv, kw = scale_inputs(g, case)
+                kwt = {k: (T(v) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+                r = (kfitter if kid_fit else fitter).fit(
+                    T(tv), requested_keys=['pose_rotvecs', 'shape_betas', 'trans', 'scale_corr'], **kwt)
+                for k in ('pose_rotvecs', 'shape_betas', 'trans', 'kid_factor', 'orientations', 'scale_corr'):
+                    if k in r:
+                        out[f'scale.{case}.{k}'] = r[k].numpy()
             # share_beta: the targets come from the repo's own numpy forward (pinned by golden_<kind>.npz)
             _, md_ = load_md(root, kind, g)
             om_, _ = make_oracle(md_, kind)

@@ -212,3 +212,25 @@ def test_share_beta_goldens(name, model_root, golden):
         tj = kw.pop('target_joints')
         o = (kf if kid_fit else of).fit(tv, tj, share_beta=True, **kw)
         util.check_share(om, name, case, o, ge, kid_fit)
+
+
+@pytest.mark.parametrize('name', ['smpl', 'smplx'])
+def test_scale_goldens(name, model_root, golden):
+    """fit(scale_target=True) / fit(scale_fit=True): one more unknown in the LAST shape solve, scaled
+    targets resp. scaled reference in the refinement, scaled mean added back (pt/bodyfitter.py:434-519,
+    :1170-1175, :1284-1296; the reference's TestFitterWithScale)."""
+    g, ge = golden(name), golden(f'ext_{name}')
+    kind, md = util.load_md(model_root, name, g)
+    om, of = util.make_oracle(md, kind)
+    kf = O.OracleFitter(om, enable_kid=True)
+    for case in util.SCALE_CASES:
+        if f'scale.{case}.trans' not in ge:
+            continue
+        kid_fit, tv, kw = util.scale_inputs(g, case)
+        kw = dict(kw)
+        tj = kw.pop('target_joints')
+        o = (kf if kid_fit else of).fit(tv, tj, **kw)
+        util.check_scale(om, name, case, o, ge, kid_fit)
+        if case in ('a', 'b'):  # the target really is a 1.1x body
+            want = 1 / 1.1 if case == 'a' else 1.1
+            assert np.abs(o['scale_corr'] - want).max() < 0.02

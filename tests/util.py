@@ -185,3 +185,39 @@ def check_share(om, name, case, o, ge, kid_fit):
     va = om.forward(o['pose_rotvecs'], o['shape_betas'], o['trans'], **kw_o)['vertices']
     vb = om.forward(ref['pose_rotvecs'], ref['shape_betas'], ref['trans'], **kw_r)['vertices']
     assert np.linalg.norm(va - vb, axis=-1).max() < 5e-4, case
+
+
+# scale_target / scale_fit of fit (the extra unknown of the LAST shape solve, reference
+# pt/bodyfitter.py:1170-1175, :1284-1296, driver :434-519; the reference's TestFitterWithScale)
+# case -> (enable_kid, scale option, joints, weights, fit kwargs)
+SCALE_CASES = {
+    'a': (False, 'scale_target', True, False, dict(num_iter=3, beta_regularizer=0.0)),
+    'b': (False, 'scale_fit', True, False, dict(num_iter=3, beta_regularizer=0.0)),
+    'c': (False, 'scale_fit', False, True, dict(num_iter=2, beta_regularizer=1.0, scale_regularizer=0.5)),
+    'd': (True, 'scale_target', True, True, dict(num_iter=2, beta_regularizer=1.0)),
+    'e': (False, 'scale_target', False, False, dict(num_iter=1, beta_regularizer=1.0, final_adjust_rots=False)),
+}
+
+
+def scale_inputs(g, case):
+    kid_fit, opt, joints, weights, kw = SCALE_CASES[case]
+    f = np.float32(1.1)
+    kw = dict(kw)
+    kw[opt] = True
+    kw['target_joints'] = g['target_joints'] * f if joints else None
+    kw['vertex_weights'] = g['vertex_weights'] if weights else None
+    kw['joint_weights'] = g['joint_weights'] if (weights and joints) else None
+    return kid_fit, g['target_vertices'] * f, kw
+
+
+def check_scale(om, name, case, o, ge, kid_fit):
+    keys = ('pose_rotvecs', 'shape_betas', 'trans', 'scale_corr') + (('kid_factor',) if kid_fit else ())
+    ref = {k: ge[f'scale.{case}.{k}'] for k in keys}
+    assert np.abs(o['scale_corr'] - ref['scale_corr']).max() < 1e-4, case  # the reference solves this system in fp32
+    assert np.abs(o['trans'] - ref['trans']).max() < 5e-5, case
+    assert np.abs(o['shape_betas'] - ref['shape_betas']).max() < (1e-3 if name == 'smpl' else 3e-3), case
+    kw_o = dict(kid_factor=o['kid_factor']) if kid_fit else {}
+    kw_r = dict(kid_factor=ref['kid_factor']) if kid_fit else {}
+    va = om.forward(o['pose_rotvecs'], o['shape_betas'], o['trans'], **kw_o)['vertices']
+    vb = om.forward(ref['pose_rotvecs'], ref['shape_betas'], ref['trans'], **kw_r)['vertices']
+    assert np.linalg.norm(va - vb, axis=-1).max() < 1e-4, case
