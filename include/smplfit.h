@@ -157,6 +157,9 @@ int smplfit_fit_warm_f32(const smplfit_handle* h, const float* target_vertices,
  *   (pt/lstsq.py:24-26 through lstsq_partial_share :32-90 with every unknown shared), every instance
  *   keeps its own translation.  The sum runs over the instances in order on one GPU; across GPUs it
  *   would be one all-reduce of (S*S + S) doubles per shape solve (not wired: smplfitter_amd.dist raises).
+ *   scale_mode -- BodyFitter.fit(scale_target=True) / (scale_fit=True): the LAST shape solve gets one more
+ *   unknown, the refinement sees scaled targets resp. a scaled reference, the mean is added back scaled.
+ *   shape_betas / kid_factor are returned as the reference returns them (undivided by the scale).
  * Zero-initialise the struct; fields left 0 / NULL mean "not given". */
 typedef struct smplfit_fit_args {
   const float* target_vertices;      /* (B,V,3) */
@@ -171,12 +174,15 @@ typedef struct smplfit_fit_args {
   int32_t num_initial_betas;
   const float* initial_kid_factor;   /* (B) or NULL */
   int32_t share_beta;
+  int32_t scale_mode;                /* 0; 1 = scale_target, 2 = scale_fit (the last solve, :434-519) */
+  float scale_regularizer;
   float* pose_rotvecs;               /* out (B,3J) */
   float* shape_betas;                /* out (B,S) */
   float* trans;                      /* out (B,3) */
   float* kid_factor;                 /* out (B) or NULL */
   float* orientations;               /* out (B,J,3,3) or NULL */
   float* relative_orientations;      /* out (B,J,3,3) or NULL */
+  float* scale_corr;                 /* out (B), required with scale_mode != 0 */
   void* workspace;
   size_t workspace_bytes;
   void* hip_stream;

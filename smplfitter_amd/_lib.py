@@ -48,9 +48,11 @@ class FitArgs(C.Structure):
         ('beta_regularizer', C.c_float), ('beta_regularizer2', C.c_float), ('kid_regularizer', C.c_float),
         ('final_adjust_rots', C.c_int32), ('initial_pose_rotvecs', C.c_void_p),
         ('initial_shape_betas', C.c_void_p), ('num_initial_betas', C.c_int32),
-        ('initial_kid_factor', C.c_void_p), ('share_beta', C.c_int32), ('pose_rotvecs', C.c_void_p),
+        ('initial_kid_factor', C.c_void_p), ('share_beta', C.c_int32), ('scale_mode', C.c_int32),
+        ('scale_regularizer', C.c_float), ('pose_rotvecs', C.c_void_p),
         ('shape_betas', C.c_void_p), ('trans', C.c_void_p), ('kid_factor', C.c_void_p),
-        ('orientations', C.c_void_p), ('relative_orientations', C.c_void_p), ('workspace', C.c_void_p),
+        ('orientations', C.c_void_p), ('relative_orientations', C.c_void_p), ('scale_corr', C.c_void_p),
+        ('workspace', C.c_void_p),
         ('workspace_bytes', C.c_size_t), ('hip_stream', C.c_void_p),
     ]
 

@@ -38,6 +38,7 @@ SF_HD constexpr int cpack_stride(int S, int KW) {
 SF_HD constexpr int rp_pos(int p, int Kp) { return (p & 1) * (Kp / 2) + (p >> 1); }
 
 constexpr int kPsum = 16;  // part-sum record: raw 9, s_t 3, s_a 3, s_w 1
+constexpr int kScaleExtras = 6;  // scaled solve: entries after u in the extra-sum record (tt, tb, bb, St)
 
 struct alignas(16) F4 {
   float x, y, z, w;
@@ -416,6 +417,166 @@ SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const doubl
     for (int s = 0; s < S; ++s) acc += pext[idx * S1 + 1 + s] * betaf[s];
     rjoints_out[idx] = pext[idx * S1] + acc + transf[c];
     // skinning translation at the solution, T0 + T' beta (vertex re-evaluation :1099-1101)
+    float tb0 = 0.f;
+    const float* tr = jd + j * stride + 12 + c * row;
+    for (int s = 0; s < S; ++s) tb0 += tr[s] * betaf[s];
+    jb_out[j * 4 + c] = jd[j * stride + 9 + c] + tb0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage S' — the LAST shape solve of fit(scale_target=True) / fit(scale_fit=True): one more unknown
+// sigma = scale - 1 (_fit_shape_general, bodyfitter.py:1104-1319; driver :434-455).  The (S+1)-unknown
+// normal equations are assembled from the ordinary record (gramv + gramj, as in stage S) and the extra
+// sums of the vertices (vextra: [u : S][tt][tb][bb][St : 3], scale_extras_vertex) and of the joints
+// (computed here from P and the target joints):
+//   scale_target (mode 1), c = -t:      g = -u,  h = tt,  q = -tb,  Sc = -St
+//   scale_fit    (mode 2), c = t - b:   g = u - r,  h = tt - 2 tb + bb,  q = tb - bb,  Sc = St - Sb
+// scratch: doubles [NE+1 | (S+1)^2 | S+1 | S | 8] then floats.  Outputs: beta_out (S, UNDIVIDED — what the
+// reference returns and hands to the refinement, :1277-1283), beta_eval (S, divided by the scale for
+// scale_fit: the shape the mesh is evaluated at, :1289-1293), trans, scale, joints, jb.
+// ---------------------------------------------------------------------------------------------
+SF_HD int scaled_solve_scratch_floats(int S) {
+  return 2 * (ne_size(S) + 1 + (S + 1) * (S + 1) + (S + 1) + S + 8) + ((S + 8) / 4 * 4);
+}
+
+template <class Ctx>
+SF_HD void scaled_solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const double* gramv,
+                              const float* gramj, const float* vextra, const float* pext, const float* jd,
+                              const float* mb, const float* tj, const float* jw, bool joint_block,
+                              int mode, float beta_reg, float beta_reg2, float kid_reg, float scale_reg,
+                              const float* reg_ref, float* beta_out, float* beta_eval, float* trans_out,
+                              float* scale_out, float* rjoints_out, float* jb_out) {
+  const int J = tb.J, S = tb.S, S1 = S + 1, N = S + 1;
+  const int NG = ne_ng(S), NE = ne_size(S);
+  double* sum = reinterpret_cast<double*>(scratch);  // NE+1
+  double* M = sum + NE + 1;                          // N*N (lower triangle)
+  double* x = M + N * N;                             // N
+  double* u = x + N;                                 // S: sum w Jac^T t, vertices + joints
+  double* ex = u + S;                                // [tt, tb, bb, St(3)] vertices + joints
+  float* aux = reinterpret_cast<float*>(ex + 8);     // S+4 floats
+  SF_FOR(e, NE + 1) {
+    double v = gramv[e] + (double)gramj[e];
+    if (mb && e >= NG && e < NG + S) {  // pair-Gram form of the vertex block (see stage S)
+      const int i = e - NG, stride = jd_stride(S), row = jd_row(S);
+      double r2 = 0.0;
+      for (int j = 0; j < J; ++j)
+        for (int c = 0; c < 3; ++c) r2 += (double)jd[j * stride + 12 + c * row + i] * (double)mb[j * 3 + c];
+      v += r2;
+    }
+    sum[e] = v;
+  }
+  // the extra sums: vertices + joints
+  SF_FOR(i, S + kScaleExtras) {
+    double v = (double)vextra[i];
+    if (joint_block) {
+      float acc = 0.f;
+      for (int j = 0; j < J; ++j) {
+        const float w = jw ? jw[j] : 1.0f;
+        for (int c = 0; c < 3; ++c) {
+          const float t = tj[j * 3 + c], p0 = pext[(j * 3 + c) * S1], b = t - p0;
+          float term;
+          if (i < S) term = pext[(j * 3 + c) * S1 + 1 + i] * t;
+          else if (i == S) term = t * t;
+          else if (i == S + 1) term = t * b;
+          else if (i == S + 2) term = b * b;
+          else term = (c == i - S - 3) ? t : 0.f;
+          acc += w * term;
+        }
+      }
+      v += (double)acc;
+    }
+    if (i < S) u[i] = v; else ex[i - S] = v;
+  }
+  cx.sync();
+  double W = sum[NE];
+  if (W == 0.0) W = 1.0;
+  const double* SA = sum + NG + S;
+  const double* Sb = sum + NG + 4 * S;
+  const double tt = ex[0], tbv = ex[1], bb = ex[2];
+  const double h = mode == 1 ? tt : tt - 2.0 * tbv + bb;
+  const double q = mode == 1 ? -tbv : tbv - bb;
+  double Sc[3];
+  for (int c = 0; c < 3; ++c) Sc[c] = mode == 1 ? -ex[3 + c] : ex[3 + c] - Sb[c];
+  auto lam = [&](int i) -> double {
+    return i == S ? (double)scale_reg : (double)(i >= S - tb.n_kid ? kid_reg : (i < 2 ? beta_reg2 : beta_reg));
+  };
+  auto gcol = [&](int i) -> double { return mode == 1 ? -u[i] : u[i] - sum[NG + i]; };  // g[i]
+  SF_FOR(idx, N * N) {
+    const int i = idx / N, j = idx % N;
+    if (j <= i) {
+      double g;
+      if (i < S) {
+        g = sum[ne_g(S, j, i)] - (SA[i] * SA[j] + SA[S + i] * SA[S + j] + SA[2 * S + i] * SA[2 * S + j]) / W;
+      } else if (j < S) {
+        g = gcol(j) - (Sc[0] * SA[j] + Sc[1] * SA[S + j] + Sc[2] * SA[2 * S + j]) / W;
+      } else {
+        g = h - (Sc[0] * Sc[0] + Sc[1] * Sc[1] + Sc[2] * Sc[2]) / W;
+      }
+      if (i == j) g += lam(i);
+      M[i * N + j] = g;
+    }
+  }
+  SF_FOR(i, N) {
+    double r;
+    if (i < S) {
+      r = sum[NG + i] - (SA[i] * Sb[0] + SA[S + i] * Sb[1] + SA[2 * S + i] * Sb[2]) / W;
+      if (reg_ref) r += lam(i) * (double)reg_ref[i];
+    } else {
+      r = q - (Sc[0] * Sb[0] + Sc[1] * Sb[1] + Sc[2] * Sb[2]) / W;
+    }
+    x[i] = r;
+  }
+  cx.sync();
+  for (int k = 0; k < N; ++k) {  // Cholesky, column by column
+    if (cx.lane == 0) M[k * N + k] = sqrt(M[k * N + k]);
+    cx.sync();
+    SF_FOR(i, N) if (i > k) M[i * N + k] /= M[k * N + k];
+    cx.sync();
+    SF_FOR(idx, N * N) {
+      const int i = idx / N, j = idx % N;
+      if (j > k && i >= j) M[i * N + j] -= M[i * N + k] * M[j * N + k];
+    }
+    cx.sync();
+  }
+  if (cx.lane == 0) {
+    for (int i = 0; i < N; ++i) {
+      double v = x[i];
+      for (int k = 0; k < i; ++k) v -= M[i * N + k] * x[k];
+      x[i] = v / M[i * N + i];
+    }
+    for (int i = N - 1; i >= 0; --i) {
+      double v = x[i];
+      for (int k = i + 1; k < N; ++k) v -= M[k * N + i] * x[k];
+      x[i] = v / M[i * N + i];
+    }
+  }
+  cx.sync();
+  float* betaf = aux;            // S: the shape the mesh is evaluated at
+  float* transf = aux + S;       // 3
+  const float scale = (float)x[S] + 1.0f;  // new_scale_corr (:1286)
+  SF_FOR(i, S) {
+    const float bu = (float)x[i];
+    beta_out[i] = bu;
+    const float be = mode == 2 ? bu / scale : bu;  // (:1289-1293)
+    betaf[i] = be;
+    beta_eval[i] = be;
+  }
+  SF_FOR(c, 3) {  // translation from ALL unknowns, sigma included (:1270-1272)
+    double v = Sb[c] / W;
+    for (int i = 0; i < S; ++i) v -= (SA[c * S + i] / W) * x[i];
+    v -= (Sc[c] / W) * x[S];
+    transf[c] = (float)v;
+    trans_out[c] = (float)v;
+  }
+  if (cx.lane == 0) scale_out[0] = scale;
+  cx.sync();
+  const int stride = jd_stride(S), row = jd_row(S);
+  SF_FOR(idx, J * 3) {
+    const int j = idx / 3, c = idx % 3;
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += pext[idx * S1 + 1 + s] * betaf[s];
+    rjoints_out[idx] = pext[idx * S1] + acc + transf[c];
     float tb0 = 0.f;
     const float* tr = jd + j * stride + 12 + c * row;
     for (int s = 0; s < S; ++s) tb0 += tr[s] * betaf[s];
@@ -814,6 +975,38 @@ SF_HD void shape_accum_vertex(const float* jd, const float* rec, const float* vp
       }
     }
   }
+}
+
+// Extra sums of the scaled shape solve (scale_target / scale_fit, _fit_shape_general
+// bodyfitter.py:1170-1175): with the scale column c = -t (scale_target) or c = pos = t - b (scale_fit)
+// every new entry of the normal equations follows from
+//   u = sum w Jac^T t,  tt = sum w |t|^2,  tb = sum w t.b,  bb = sum w |b|^2,  St = sum w t
+// (see scaled_solve_stage).  acc: [u : S][tt][tb][bb][St : 3].
+template <int S, int KW>
+SF_HD void scale_extras_vertex(const float* jd, const float* rec, const float* vp, const float* tv,
+                               float wv, float* acc) {
+  constexpr int STRIDE = jd_stride(S), ROW = jd_row(S);
+  const Skin<KW> sk = skin_from_rec<S, KW>(rec);
+  float Rt[9], T0[3];
+  blend_rt<S, KW>(jd, sk, Rt, T0);
+  float bq = 0.f, tq = 0.f, tbq = 0.f;
+  for (int c = 0; c < 3; ++c) {
+    const float pos = (Rt[c * 3] * vp[0] + Rt[c * 3 + 1] * vp[1] + Rt[c * 3 + 2] * vp[2]) + T0[c];
+    const float b = tv[c] - pos;
+    tq += tv[c] * tv[c];
+    tbq += tv[c] * b;
+    bq += b * b;
+    acc[S + 3 + c] += wv * tv[c];
+    const float wt = wv * tv[c];
+    for (int s = 0; s < S; ++s) {
+      float a = Rt[c * 3] * rec[s * 3] + Rt[c * 3 + 1] * rec[s * 3 + 1] + Rt[c * 3 + 2] * rec[s * 3 + 2];
+      for (int k = 0; k < KW; ++k) a += sk.w[k] * jd[sk.j[k] * STRIDE + 12 + c * ROW + s];
+      acc[s] += wt * a;
+    }
+  }
+  acc[S] += wv * tq;
+  acc[S + 1] += wv * tbq;
+  acc[S + 2] += wv * bq;
 }
 
 // Vertex at the solved shape (bodyfitter.py:1099-1101; LBS of bodymodel.py:288-306):

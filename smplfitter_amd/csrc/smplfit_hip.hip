@@ -139,6 +139,9 @@ struct Workspace {
   float* scale;    // (B) scale_corr of the known-shape fit
   float* regref;   // (B,S) ridge reference of the warm-started fit
   double* cen;     // (B, S*S+S) centred regularised systems of a share_beta fit; row B = their sum
+  float* vextra;   // (B,32) extra vertex sums of the scaled solve (scale_extras_vertex)
+  float* beta_out; // (B,S) undivided shape of the scaled solve (ws.beta holds the evaluated one)
+  float* tjs;      // (B,J,3) target joints times the scale (scale_target refinement)
   // batch-major path: streams with the instance index innermost (lane = instance reads coalesce)
   float* vpT;      // (Mp/64, 3*Vp, 64) v_posed, written by the GEMM
   float* tT;       // (Mp/64, 3*Vp, 64) centred targets, transposed from tvs
@@ -182,6 +185,9 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w) {
   ws.scale = (float*)take((size_t)B * 4);
   ws.regref = (float*)take((size_t)B * S * 4);
   ws.cen = (double*)take(((size_t)B + 1) * (S * S + S) * 8);
+  ws.vextra = (float*)take((size_t)B * 32 * 4);
+  ws.beta_out = (float*)take((size_t)B * S * 4);
+  ws.tjs = (float*)take((size_t)B * J * 3 * 4);
   ws.vpT = (float*)take(Mp * 3 * Vp * 4);
   ws.tT = (float*)take(Mp * 3 * Vp * 4);
   ws.psumP = (float*)take((size_t)t.groups.size() * 16 * Mp * 4);
@@ -913,6 +919,94 @@ __global__ __launch_bounds__(64) void k_shape_solve(DevModel m, Workspace ws, fl
                   ws.beta + (size_t)b * S, ws.trans + (size_t)b * 3, ws.rjoints + (size_t)b * J * 3,
                   ws.jb + (size_t)b * J * 4, use_ref ? ws.regref + (size_t)b * S : nullptr, mode,
                   mode == 1 ? ws.cen + (size_t)b * (S * S + S) : ws.cen + (size_t)B * (S * S + S));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scaled last solve of fit(scale_target / scale_fit) — a niche option, kept simple: one wave per
+// instance for the extra vertex sums (joint block in LDS, records and streams straight from L2/HBM).
+// ------------------------------------------------------------------------------------------------
+template <int S, int KW>
+__global__ __launch_bounds__(64) void k_scale_extras(DevModel m, Workspace ws, int weighted) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int STRIDE = sf::jd_stride(S), CS = sf::cpack_stride(S, KW), NX = S + sf::kScaleExtras;
+  const int b = blockIdx.x, lane = threadIdx.x, J = m.J, Vp = m.Vp;
+  for (int k = lane; k < J * STRIDE; k += 64) smem[k] = ws.jd[(size_t)b * J * STRIDE + k];
+  __syncthreads();
+  const float* tvs = ws.tvs + (size_t)b * 3 * Vp;
+  const float* vps = ws.vposed + (size_t)b * 3 * Vp;
+  float acc[NX];
+#pragma unroll
+  for (int k = 0; k < NX; ++k) acc[k] = 0.f;
+  for (int i = lane; i < m.V; i += 64) {  // slots [0, V) are the real vertices
+    const float vp[3] = {vps[i], vps[Vp + i], vps[2 * Vp + i]};
+    const float tv[3] = {tvs[i], tvs[Vp + i], tvs[2 * Vp + i]};
+    const float wv = weighted ? ws.vws[(size_t)b * Vp + i] : 1.f;
+    sf::scale_extras_vertex<S, KW>(smem, m.cpackA + (size_t)i * CS, vp, tv, wv, acc);
+  }
+#pragma unroll
+  for (int k = 0; k < NX; ++k) {
+    const float r = wave_sum(acc[k]);
+    if (lane == 0) ws.vextra[(size_t)b * 32 + k] = r;
+  }
+}
+
+struct ScaledSolveArgs {
+  const float* tj;  // centred target joints (joint block) or null
+  const float* jw;  // joint weights entering the solve or null
+  int joint_block, mode, pair_form, use_ref;
+  float beta_reg, beta_reg2, kid_reg, scale_reg;
+};
+
+__global__ __launch_bounds__(64) void k_shape_solve_scaled(DevModel m, Workspace ws, ScaledSolveArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x, J = m.J, S = m.S;
+  DevCtx cx{(int)threadIdx.x, 64};
+  const int NE1 = sf::ne_size(S) + 1;
+  sf::scaled_solve_stage(cx, m.jt, smem, ws.gramv + (size_t)b * NE1, ws.gramj + (size_t)b * NE1,
+                         ws.vextra + (size_t)b * 32, ws.pext + (size_t)b * J * 3 * (S + 1),
+                         ws.jd + (size_t)b * J * sf::jd_stride(S),
+                         a.pair_form ? ws.mbj + (size_t)b * J * 3 : nullptr,
+                         a.tj ? a.tj + (size_t)b * J * 3 : nullptr, a.jw ? a.jw + (size_t)b * J : nullptr,
+                         a.joint_block != 0, a.mode, a.beta_reg, a.beta_reg2, a.kid_reg, a.scale_reg,
+                         a.use_ref ? ws.regref + (size_t)b * S : nullptr, ws.beta_out + (size_t)b * S,
+                         ws.beta + (size_t)b * S, ws.trans + (size_t)b * 3, ws.scale + b,
+                         ws.rjoints + (size_t)b * J * 3, ws.jb + (size_t)b * J * 4);
+}
+
+// After the scaled solve (and the LBS pass when the refinement follows): what the refinement and the
+// epilogue see (bodyfitter.py:462-519).
+//   scale_target: targets x s -> part sums raw, s_t x s, target joints x s; mean x s
+//   scale_fit:    reference <- s reference + (1 - s) trans -> raw, s_a, reference joints; mean / s
+// and the undivided shape back into ws.beta.  grid B, block 64.
+__global__ __launch_bounds__(64) void k_scale_refs(DevModel m, Workspace ws, const float* __restrict__ tj_in,
+                                                   int mode, int have_psum, int regressed) {
+  const int b = blockIdx.x, lane = threadIdx.x, J = m.J, S = m.S;
+  const float s = ws.scale[b];
+  const float tr[3] = {(1.f - s) * ws.trans[b * 3], (1.f - s) * ws.trans[b * 3 + 1],
+                       (1.f - s) * ws.trans[b * 3 + 2]};
+  if (have_psum) {
+    for (int j = lane; j < J; j += 64) {
+      float* ps = ws.psum + ((size_t)b * J + j) * sf::kPsum;
+      if (mode == 1) {
+        for (int k = 0; k < 12; ++k) ps[k] *= s;  // raw and s_t are linear in the targets
+        for (int c = 0; c < 3; ++c) ws.tjs[((size_t)b * J + j) * 3 + c] = s * tj_in[((size_t)b * J + j) * 3 + c];
+      } else {
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c < 3; ++c) ps[r * 3 + c] = s * ps[r * 3 + c] + ps[9 + r] * tr[c];
+        for (int c = 0; c < 3; ++c) {
+          ps[12 + c] = s * ps[12 + c] + ps[15] * tr[c];
+          float* rj = ws.rjoints + ((size_t)b * J + j) * 3 + c;
+          *rj = s * *rj + tr[c];
+          if (regressed) {
+            float* rr = ws.rjreg + ((size_t)b * J + j) * 3 + c;
+            *rr = s * *rr + m.reg_rowsum[j] * tr[c];
+          }
+        }
+      }
+    }
+  }
+  if (lane < S) ws.beta[(size_t)b * S + lane] = ws.beta_out[(size_t)b * S + lane];
+  if (lane < 3) ws.mean[b * 3 + lane] = mode == 1 ? ws.mean[b * 3 + lane] * s : ws.mean[b * 3 + lane] / s;
 }
 
 // share_beta: sum of the per-instance systems over the batch, instances in order (deterministic);
@@ -1953,6 +2047,9 @@ struct FitOptions {
   int init_nb = 0;
   const float* init_kid = nullptr;    // (B) or null
   int share_beta = 0;                 // one shape for the whole batch (pt/lstsq.py:24-26)
+  int scale_mode = 0;                 // 1 scale_target, 2 scale_fit: the last solve has a scale unknown
+  float scale_reg = 0.f;
+  float* scale_out = nullptr;         // (B) scale_corr
 };
 
 int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const float* vw,
@@ -1969,7 +2066,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   const bool eff_v = joints ? (vw && jw) : (vw != nullptr);
   const bool eff_j = joints && vw && jw;
   launch_center_sort(d, tv, tj, vw, ws, B, st);
-  const bool bm = bm_applies(d) && joints && !vw && !o.rotations_only;
+  const bool bm = bm_applies(d) && joints && !vw && !o.rotations_only && !o.scale_mode;
   if (bm) {
     const int Mp = (int)align_up((size_t)B, 128), N = 3 * d.Vp;
     hipLaunchKernelGGL(k_transpose_targets, dim3(N / 64, Mp / 64), dim3(256), 0, st, ws.tvs, ws.tT, B, N, Mp);
@@ -2043,7 +2140,24 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     // K4 stays its own launch: fused into the prologue of the LBS kernel (template flag SOLVE) its
     // ~40 serial barriers stall all four waves of the workgroup and the kernel ran 230 us longer
     const int pair_in = (bm || (!eff_v && use_pair_form())) ? 1 : 0;
-    if (o.share_beta) {  // assemble per instance, sum over the batch, solve the sum + own translation
+    const bool scaled_now = o.scale_mode && it + 1 == o.num_iter;  // only the last solve (:434-455)
+    if (scaled_now) {
+#define SF_CALL_EXTRAS(S_, KW_)                                                                       \
+  hipLaunchKernelGGL((k_scale_extras<S_, KW_>), dim3(B), dim3(64),                                    \
+                     (size_t)d.J * sf::jd_stride(S_) * 4, st, d, ws, eff_v ? 1 : 0)
+      SF_DISPATCH_SKW(d, SF_CALL_EXTRAS);
+#undef SF_CALL_EXTRAS
+      ScaledSolveArgs sa{};
+      sa.tj = joints ? ws.tjc : nullptr;
+      sa.jw = eff_j ? jw : nullptr;
+      sa.joint_block = joints ? 1 : 0;
+      sa.mode = o.scale_mode;
+      sa.pair_form = pair_in;
+      sa.use_ref = use_ref;
+      sa.beta_reg = o.beta_reg; sa.beta_reg2 = o.beta_reg2; sa.kid_reg = o.kid_reg; sa.scale_reg = o.scale_reg;
+      hipLaunchKernelGGL(k_shape_solve_scaled, dim3(B), dim3(64),
+                         (size_t)sf::scaled_solve_scratch_floats(d.S) * 4, st, d, ws, sa);
+    } else if (o.share_beta) {  // assemble per instance, sum over the batch, solve the sum + own translation
       const int NC = d.S * d.S + d.S;
       hipLaunchKernelGGL(k_shape_solve, dim3(B), dim3(64), solve_lds(d), st, d, ws, o.beta_reg,
                          o.beta_reg2, o.kid_reg, pair_in, use_ref, 1, B);
@@ -2089,6 +2203,14 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   ra.kid = kid;
   ra.orient = orient;
   ra.rel = rel;
+  if (o.scale_mode) {
+    hipLaunchKernelGGL(k_scale_refs, dim3(B), dim3(64), 0, st, d, ws, tj_rot, o.scale_mode,
+                       o.final_adjust ? 1 : 0, joints ? 0 : 1);
+    if (o.scale_mode == 1 && o.final_adjust) ra.tj = ws.tjs;  // target joints times the scale
+    ra.scaled = o.scale_mode == 2 ? 1 : 0;                      // rest joints times the scale (:1449-1450)
+    if (o.scale_out)
+      hipLaunchKernelGGL(k_copy, dim3(16), dim3(256), 0, st, ws.scale, o.scale_out, (size_t)B);
+  }
   hipLaunchKernelGGL(k_refine_epilogue, dim3(B), dim3(64), joint_lds(d, 1), st, d, ra, ws);
   return post_launch_check();
 }
@@ -2487,6 +2609,16 @@ int smplfit_fit_ex_f32(const smplfit_handle* h, const smplfit_fit_args* args) {
   FitOptions o{num_iter, beta_regularizer, beta_regularizer2, kid_regularizer,
                final_adjust_rots ? 1 : 0, 0};
   o.share_beta = args->share_beta ? 1 : 0;
+  if (args->scale_mode < 0 || args->scale_mode > 2)
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_ex_f32: scale_mode must be 0, 1 (scale_target) or 2 (scale_fit)");
+  if (args->scale_mode && !args->scale_corr)
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_ex_f32: a scale option needs the scale_corr output");
+  if (args->scale_mode && o.share_beta)
+    return fail(SMPLFIT_ERR_UNSUPPORTED,
+                "smplfit_fit_ex_f32: share_beta together with a scale unknown (partially shared solve, "
+                "pt/lstsq.py:32-90) is not implemented");
+  o.scale_mode = args->scale_mode;
+  o.scale_reg = args->scale_regularizer;
   hipStream_t st = (hipStream_t)hip_stream;
   int sizes[kMaxChunks];
   // share_beta couples all instances in every shape solve: one chunk
@@ -2500,6 +2632,7 @@ int smplfit_fit_ex_f32(const smplfit_handle* h, const smplfit_fit_args* args) {
     oc.init_betas = initial_shape_betas ? initial_shape_betas + (size_t)b0 * inb : nullptr;
     oc.init_nb = inb;
     oc.init_kid = initial_kid_factor ? initial_kid_factor + b0 : nullptr;
+    oc.scale_out = args->scale_corr ? args->scale_corr + b0 : nullptr;
     return run_fit(h, target_vertices + (size_t)b0 * V * 3,
                    target_joints ? target_joints + (size_t)b0 * J * 3 : nullptr,
                    vertex_weights ? vertex_weights + (size_t)b0 * V : nullptr,

@@ -40,7 +40,7 @@ class BodyFitter(nn.Module):
         if share_beta:
             unsupported.append('share_beta (outside fit)')
         if scale_target or scale_fit:
-            unsupported.append('scale_target/scale_fit')
+            unsupported.append('scale_target/scale_fit (outside fit)')
         if beta_ref is not None or kid_ref is not None:
             unsupported.append('beta/kid_regularizer_reference')
         if unsupported:
@@ -76,27 +76,37 @@ class BodyFitter(nn.Module):
         warm-start the fit (``smplfit_fit_warm_f32``; reference :363-382)."""
         if requested_keys is None:
             requested_keys = ['pose_rotvecs']
-        self._check_options(False, scale_target, scale_fit)  # share_beta: smplfit_fit_ex_f32
+        self._check_options(False, False, False)  # share_beta / scale options: smplfit_fit_ex_f32
+        if scale_target and scale_fit:  # same check, same message as pt/bodyfitter.py:858-859
+            raise ValueError('Only one of estim_scale_target and estim_scale_fit can be True')
+        if share_beta and (scale_target or scale_fit):
+            raise NotImplementedError('share_beta together with a scale unknown (partially shared solve, '
+                                      'pt/lstsq.py:32-90) is not implemented')
+        scale_mode = 1 if scale_target else 2 if scale_fit else 0
         if initial_kid_factor is not None and not self.enable_kid:
             raise NotImplementedError(
                 'initial_kid_factor needs BodyFitter(enable_kid=True) on the HIP path')
         # the reference defaults the kid ridge weight to beta_regularizer (pt/bodyfitter.py:1235-1237)
         kid_reg = float(beta_regularizer if kid_regularizer is None else kid_regularizer)
         if torch.compiler.is_compiling():  # one opaque operator for torch.compile / export
-            pose, betas, trans, kid, orient, rel = torch.ops.smplfitter_amd.fit(
+            pose, betas, trans, kid, orient, rel, scale = torch.ops.smplfitter_amd.fit(
                 self.body_model._model_id, self.enable_kid, target_vertices, target_joints,
                 vertex_weights, joint_weights, int(num_iter), float(beta_regularizer),
                 float(beta_regularizer2), kid_reg, bool(final_adjust_rots), initial_pose_rotvecs,
-                initial_shape_betas, initial_kid_factor, bool(share_beta))
+                initial_shape_betas, initial_kid_factor, bool(share_beta), scale_mode,
+                float(scale_regularizer))
             result = dict(pose_rotvecs=pose, shape_betas=betas, trans=trans, orientations=orient,
                           relative_orientations=rel)
             if self.enable_kid:
                 result['kid_factor'] = kid
+            if scale_mode:
+                result['scale_corr'] = scale
         else:
             result = self._fit_direct(target_vertices, target_joints, vertex_weights, joint_weights,
                                       num_iter, beta_regularizer, beta_regularizer2, kid_reg,
                                       final_adjust_rots, initial_pose_rotvecs, initial_shape_betas,
-                                      initial_kid_factor, _workspace, share_beta)
+                                      initial_kid_factor, _workspace, share_beta, scale_mode,
+                                      scale_regularizer)
         # relative_orientations = parent^T @ global of the FINAL rotations (pt/bodyfitter.py:523-533);
         # returned always (the reference returns the pre-refinement ones when neither
         # 'relative_orientations' nor 'pose_rotvecs' is requested)
@@ -107,7 +117,7 @@ class BodyFitter(nn.Module):
     def _fit_direct(self, target_vertices, target_joints, vertex_weights, joint_weights, num_iter,
                     beta_regularizer, beta_regularizer2, kid_reg, final_adjust_rots,
                     initial_pose_rotvecs, initial_shape_betas, initial_kid_factor, _workspace,
-                    share_beta=False):
+                    share_beta=False, scale_mode=0, scale_regularizer=0.0):
         """The C-ABI call behind ``fit`` (and behind the ``smplfitter_amd::fit`` operator): every result
         tensor, ``pose_rotvecs`` included."""
         bm = self.body_model
@@ -139,6 +149,7 @@ class BodyFitter(nn.Module):
         orient = torch.empty((B, J, 3, 3), dtype=torch.float32, device=device)
         rel = torch.empty((B, J, 3, 3), dtype=torch.float32, device=device)
         kid = torch.empty((B,), dtype=torch.float32, device=device) if self.enable_kid else None
+        scale = torch.empty((B,), dtype=torch.float32, device=device) if scale_mode else None
         if B > 0:
             h = bm._native(device, kid=self.enable_kid)
             ws = _workspace if _workspace is not None else bm._workspace(h, B, device)
@@ -154,16 +165,20 @@ class BodyFitter(nn.Module):
                     initial_shape_betas=init_betas.data_ptr() if init_betas is not None else None,
                     num_initial_betas=0 if init_betas is None else init_betas.shape[1],
                     initial_kid_factor=init_kid.data_ptr() if init_kid is not None else None,
-                    share_beta=int(bool(share_beta)), pose_rotvecs=pose.data_ptr(),
+                    share_beta=int(bool(share_beta)), scale_mode=int(scale_mode),
+                    scale_regularizer=float(scale_regularizer), pose_rotvecs=pose.data_ptr(),
                     shape_betas=betas.data_ptr(), trans=trans.data_ptr(),
                     kid_factor=kid.data_ptr() if kid is not None else None, orientations=orient.data_ptr(),
-                    relative_orientations=rel.data_ptr(), workspace=ws.data_ptr(),
+                    relative_orientations=rel.data_ptr(),
+                    scale_corr=scale.data_ptr() if scale is not None else None, workspace=ws.data_ptr(),
                     workspace_bytes=ws.numel(), hip_stream=stream)
                 _lib.check(_lib.load().smplfit_fit_ex_f32(h.ptr, C.byref(args)))
         result = dict(pose_rotvecs=pose, shape_betas=betas, trans=trans, orientations=orient,
                       relative_orientations=rel)
         if self.enable_kid:
             result['kid_factor'] = kid
+        if scale_mode:
+            result['scale_corr'] = scale
         return result
 
 

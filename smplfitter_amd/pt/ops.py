@@ -56,27 +56,29 @@ def fit(
     vertex_weights: Optional[torch.Tensor], joint_weights: Optional[torch.Tensor], num_iter: int,
     beta_regularizer: float, beta_regularizer2: float, kid_regularizer: float, final_adjust_rots: bool,
     initial_pose_rotvecs: Optional[torch.Tensor], initial_shape_betas: Optional[torch.Tensor],
-    initial_kid_factor: Optional[torch.Tensor], share_beta: bool,
+    initial_kid_factor: Optional[torch.Tensor], share_beta: bool, scale_mode: int, scale_regularizer: float,
 ) -> List[torch.Tensor]:
     """[pose_rotvecs (B,3J), shape_betas (B,S), trans (B,3), kid_factor (B) (zeros without enable_kid),
-    orientations (B,J,3,3), relative_orientations (B,J,3,3)]."""
+    orientations (B,J,3,3), relative_orientations (B,J,3,3), scale_corr (B) (empty without a scale option)]."""
     r = _fitter(model_id, enable_kid)._fit_direct(
         target_vertices, target_joints, vertex_weights, joint_weights, num_iter, beta_regularizer,
         beta_regularizer2, kid_regularizer, final_adjust_rots, initial_pose_rotvecs, initial_shape_betas,
-        initial_kid_factor, None, share_beta)
+        initial_kid_factor, None, share_beta, scale_mode, scale_regularizer)
     kid = r['kid_factor'] if enable_kid else r['trans'].new_zeros((r['trans'].shape[0],))
+    scale = r['scale_corr'] if scale_mode else r['trans'].new_zeros((0,))
     return [r['pose_rotvecs'], r['shape_betas'], r['trans'], kid, r['orientations'],
-            r['relative_orientations']]
+            r['relative_orientations'], scale]
 
 
 @fit.register_fake
 def _(model_id, enable_kid, target_vertices, target_joints, vertex_weights, joint_weights, num_iter,
       beta_regularizer, beta_regularizer2, kid_regularizer, final_adjust_rots, initial_pose_rotvecs,
-      initial_shape_betas, initial_kid_factor, share_beta):
+      initial_shape_betas, initial_kid_factor, share_beta, scale_mode, scale_regularizer):
     m = _model(model_id)
     B, J, S = target_vertices.shape[0], m.num_joints, m.num_betas
     new = lambda *s: target_vertices.new_empty(s, dtype=torch.float32)  # noqa: E731
-    return [new(B, 3 * J), new(B, S), new(B, 3), new(B), new(B, J, 3, 3), new(B, J, 3, 3)]
+    return [new(B, 3 * J), new(B, S), new(B, 3), new(B), new(B, J, 3, 3), new(B, J, 3, 3),
+            new(B if scale_mode else 0)]
 
 
 @custom_op('smplfitter_amd::forward', mutates_args=())

@@ -292,6 +292,9 @@ struct Warm {  // warm start of fit (mirrors FitOptions::init_* in smplfit_hip.h
   int nb = 0;
   const float* kid = nullptr;
   int share_beta = 0;
+  int scale_mode = 0;  // 1 scale_target, 2 scale_fit
+  float scale_reg = 0.f;
+  float* scale_out = nullptr;
 };
 thread_local Warm g_warm;  // set by hostemu_fit_warm around hostemu_fit
 
@@ -346,11 +349,48 @@ int fit_impl(const sf::HostTables& t, const float* tv, const float* tj, const fl
     e.k1(tj_rot, rj0.data(), true, nullptr, jw, true, true, joints, eff_j, !eff_v);
   }
   if (G0_out) std::memcpy(G0_out, e.G.data(), sizeof(float) * (size_t)B * t.J * 9);
+  std::vector<float> scale, beta_und, tjs;
   for (int it = 0; it < num_iter; ++it) {
     e.gemm();
     e.k3(eff_v);
-    e.k4(reg, reg2, kid_reg);
     const bool last = it + 1 == num_iter;
+    if (w.scale_mode && last) {  // mirrors k_scale_extras + k_shape_solve_scaled
+      HostCtx cx0;
+      const int NE1 = sf::ne_size(S) + 1, NX = S + sf::kScaleExtras, Vp = t.Vp;
+      scale.assign(B, 1.f);
+      beta_und.assign((size_t)B * S, 0.f);
+      std::vector<float> scratch(sf::scaled_solve_scratch_floats(S) + 8);
+      float* sb = scratch.data();
+      while ((uintptr_t)sb & 15) ++sb;
+      for (int b = 0; b < B; ++b) {
+        std::vector<double> dacc(NX, 0.0);
+        for (int i0 = 0; i0 < t.V; i0 += 64) {  // per-lane fp32 partials as on the GPU, then summed
+          for (int i = i0; i < i0 + 64 && i < t.V; ++i) {
+            float acc[NX];
+            for (int k = 0; k < NX; ++k) acc[k] = 0.f;
+            const float vp[3] = {e.vposed[((size_t)b * 3) * Vp + i], e.vposed[((size_t)b * 3 + 1) * Vp + i],
+                                 e.vposed[((size_t)b * 3 + 2) * Vp + i]};
+            const float tvv[3] = {e.tvs[((size_t)b * 3) * Vp + i], e.tvs[((size_t)b * 3 + 1) * Vp + i],
+                                  e.tvs[((size_t)b * 3 + 2) * Vp + i]};
+            sf::scale_extras_vertex<S, KW>(e.jd_b(b), e.rec(i), vp, tvv, eff_v ? e.vws[(size_t)b * Vp + i] : 1.f, acc);
+            for (int k = 0; k < NX; ++k) dacc[k] += (double)acc[k];
+          }
+        }
+        float vextra[32];
+        for (int k = 0; k < NX; ++k) vextra[k] = (float)dacc[k];
+        sf::scaled_solve_stage(cx0, e.jt, sb, e.gramv.data() + (size_t)b * NE1, e.gramj.data() + (size_t)b * NE1,
+                               vextra, e.pext.data() + (size_t)b * t.J * 3 * (S + 1), e.jd_b(b),
+                               e.use_pair_gram ? e.mbj.data() + (size_t)b * t.J * 3 : nullptr,
+                               joints ? e.tjc.data() + (size_t)b * t.J * 3 : nullptr,
+                               eff_j ? jw + (size_t)b * t.J : nullptr, joints, w.scale_mode, reg, reg2, kid_reg,
+                               w.scale_reg, e.regref.empty() ? nullptr : e.regref.data() + (size_t)b * S,
+                               beta_und.data() + (size_t)b * S, e.beta.data() + (size_t)b * S,
+                               e.trans.data() + (size_t)b * 3, scale.data() + b,
+                               e.rjoints.data() + (size_t)b * t.J * 3, e.jb.data() + (size_t)b * t.J * 4);
+      }
+    } else {
+      e.k4(reg, reg2, kid_reg);
+    }
     if (last && !final_adjust) break;
     e.k5(vw != nullptr, !joints);
     if (!joints) e.regress(e.rverts.data(), false, e.rjreg.data(), B);
@@ -360,15 +400,49 @@ int fit_impl(const sf::HostTables& t, const float* tv, const float* tj, const fl
          joints, eff_j, !eff_v);
   }
   HostCtx cx;
+  const float* tj_ref = tj_rot;
+  if (w.scale_mode) {  // mirrors k_scale_refs
+    const int J = t.J;
+    tjs.assign(tj_rot, tj_rot + (size_t)B * J * 3);
+    for (int b = 0; b < B; ++b) {
+      const float sc = scale[b];
+      const float tr[3] = {(1.f - sc) * e.trans[b * 3], (1.f - sc) * e.trans[b * 3 + 1], (1.f - sc) * e.trans[b * 3 + 2]};
+      if (final_adjust)
+        for (int j = 0; j < J; ++j) {
+          float* ps = e.psum.data() + ((size_t)b * J + j) * sf::kPsum;
+          if (w.scale_mode == 1) {
+            for (int k = 0; k < 12; ++k) ps[k] *= sc;
+            for (int c = 0; c < 3; ++c) tjs[((size_t)b * J + j) * 3 + c] = sc * tj_rot[((size_t)b * J + j) * 3 + c];
+          } else {
+            for (int r = 0; r < 3; ++r)
+              for (int c = 0; c < 3; ++c) ps[r * 3 + c] = sc * ps[r * 3 + c] + ps[9 + r] * tr[c];
+            for (int c = 0; c < 3; ++c) {
+              ps[12 + c] = sc * ps[12 + c] + ps[15] * tr[c];
+              float& rj = e.rjoints[((size_t)b * J + j) * 3 + c];
+              rj = sc * rj + tr[c];
+              if (!joints) {
+                float& rr = e.rjreg[((size_t)b * J + j) * 3 + c];
+                rr = sc * rr + t.reg_rowsum[j] * tr[c];
+              }
+            }
+          }
+        }
+      for (int s2 = 0; s2 < S; ++s2) e.beta[(size_t)b * S + s2] = beta_und[(size_t)b * S + s2];
+      for (int c = 0; c < 3; ++c) e.mean[b * 3 + c] = w.scale_mode == 1 ? e.mean[b * 3 + c] * sc : e.mean[b * 3 + c] / sc;
+      if (w.scale_out) w.scale_out[b] = sc;
+    }
+    if (w.scale_mode == 1 && final_adjust) tj_ref = tjs.data();
+  }
   for (int b = 0; b < B; ++b)
     sf::refine_stage(cx, e.jt, e.sh, e.psum.data() + (size_t)b * t.J * sf::kPsum,
-                     tj_rot + (size_t)b * t.J * 3,
+                     tj_ref + (size_t)b * t.J * 3,
                      (joints ? e.rjoints.data() : e.rjreg.data()) + (size_t)b * t.J * 3,
                      e.rjoints.data() + (size_t)b * t.J * 3, jw ? jw + (size_t)b * t.J : nullptr,
                      e.G.data() + (size_t)b * t.J * 9, e.beta.data() + (size_t)b * S,
                      e.trans.data() + (size_t)b * 3, e.mean.data() + (size_t)b * 3, final_adjust != 0,
                      pose + (size_t)b * t.J * 3, betas + (size_t)b * (S - t.n_kid), trans + (size_t)b * 3,
-                     kid ? kid + b : nullptr, orient ? orient + (size_t)b * t.J * 9 : nullptr, nullptr);
+                     kid ? kid + b : nullptr, orient ? orient + (size_t)b * t.J * 9 : nullptr, nullptr,
+                     w.scale_mode == 2 ? scale.data() + b : nullptr);
   return 0;
 }
 
@@ -505,9 +579,12 @@ int hostemu_fit(const smplfit_model_desc* d, const float* tv, const float* tj, c
 int hostemu_fit_warm(const smplfit_model_desc* d, const float* tv, const float* tj, const float* vw,
                      const float* jw, int B, int num_iter, float reg, float reg2, float kid_reg,
                      int final_adjust, const float* init_pose, const float* init_betas, int init_nb,
-                     const float* init_kid, int share_beta, float* pose, float* betas, float* trans,
-                     float* kid, float* orient) {
+                     const float* init_kid, int share_beta, int scale_mode, float scale_reg,
+                     float* scale_out, float* pose, float* betas, float* trans, float* kid, float* orient) {
   g_warm.share_beta = share_beta;
+  g_warm.scale_mode = scale_mode;
+  g_warm.scale_reg = scale_reg;
+  g_warm.scale_out = scale_out;
   g_warm.pose = init_pose;
   g_warm.betas = init_betas;
   g_warm.nb = init_betas ? init_nb : 0;

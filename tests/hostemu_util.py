@@ -38,7 +38,7 @@ def load():
     lib.hostemu_fit.restype = i32
     lib.hostemu_forward.argtypes = [C.POINTER(_lib.ModelDesc), vp, vp, vp, i32, vp, vp, i32, vp, vp, vp]
     lib.hostemu_forward.restype = i32
-    lib.hostemu_fit_warm.argtypes = [C.POINTER(_lib.ModelDesc), vp, vp, vp, vp, i32, i32, f32, f32, f32, i32, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]
+    lib.hostemu_fit_warm.argtypes = [C.POINTER(_lib.ModelDesc), vp, vp, vp, vp, i32, i32, f32, f32, f32, i32, vp, vp, i32, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp]
     lib.hostemu_fit_warm.restype = i32
     lib.hostemu_fit_known_shape.argtypes = [C.POINTER(_lib.ModelDesc), vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.hostemu_fit_known_shape.restype = i32
@@ -135,7 +135,8 @@ def fit_known_shape(md, kind, betas, tv, target_joints=None, vertex_weights=None
 def fit_warm(md, kind, tv, target_joints=None, vertex_weights=None, joint_weights=None, num_iter=1,
              beta_regularizer=1.0, beta_regularizer2=0.0, final_adjust_rots=True, enable_kid=False,
              kid_regularizer=None, initial_pose_rotvecs=None, initial_shape_betas=None,
-             initial_kid_factor=None, share_beta=False):
+             initial_kid_factor=None, share_beta=False, scale_target=False, scale_fit=False,
+             scale_regularizer=0.0):
     lib = load()
     desc, keep = desc_from_md(md, kind, enable_kid)
     if kid_regularizer is None:
@@ -149,13 +150,18 @@ def fit_warm(md, kind, tv, target_joints=None, vertex_weights=None, joint_weight
     trans = np.zeros((B, 3), np.float32)
     orient = np.zeros((B, J, 3, 3), np.float32)
     kid = np.zeros((B,), np.float32)
+    scale = np.ones((B,), np.float32)
+    scale_mode = 1 if scale_target else 2 if scale_fit else 0
     rc = lib.hostemu_fit_warm(C.byref(desc), _p(tv), _p(tj), _p(vw), _p(jw), B, num_iter, beta_regularizer,
                               beta_regularizer2, kid_regularizer, int(final_adjust_rots), _p(ip), _p(ib),
-                              0 if ib is None else ib.shape[1], _p(ik), int(share_beta), _p(pose), _p(betas), _p(trans),
+                              0 if ib is None else ib.shape[1], _p(ik), int(share_beta), scale_mode, scale_regularizer,
+                              _p(scale), _p(pose), _p(betas), _p(trans),
                               _p(kid), _p(orient))
     if rc != 0:
         raise RuntimeError(lib.hostemu_last_error().decode())
     out = dict(pose_rotvecs=pose, shape_betas=betas, trans=trans, orientations=orient)
     if enable_kid:
         out['kid_factor'] = kid
+    if scale_mode:
+        out['scale_corr'] = scale
     return out

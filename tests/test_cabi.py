@@ -134,7 +134,7 @@ def test_torch_library_operators_registered(model_root):
     with FakeTensorMode():
         tv = torch.empty((5, m.num_vertices, 3))
         out = torch.ops.smplfitter_amd.fit(mid, False, tv, None, None, None, 3, 1.0, 0.0, 1.0, True, None,
-                                           None, None, False)
-        assert [tuple(t.shape) for t in out] == [(5, 72), (5, 10), (5, 3), (5,), (5, 24, 3, 3), (5, 24, 3, 3)]
+                                           None, None, False, 0, 0.0)
+        assert [tuple(t.shape) for t in out] == [(5, 72), (5, 10), (5, 3), (5,), (5, 24, 3, 3), (5, 24, 3, 3), (0,)]
         fw = torch.ops.smplfitter_amd.forward(mid, torch.empty((5, 72)), None, None, None, None, None, True)
         assert [tuple(t.shape) for t in fw] == [(5, 24, 3), (5, 24, 3, 3), (5, m.num_vertices, 3)]

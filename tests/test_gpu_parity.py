@@ -160,7 +160,7 @@ def test_edge_batches(model_root, golden, dev):
     with pytest.raises(ValueError):
         f.fit(tv, tj, scale_target=True, scale_fit=True)
     with pytest.raises(NotImplementedError):
-        f.fit(tv, tj, scale_fit=True)
+        f.fit(tv, tj, scale_fit=True, share_beta=True)
     with pytest.raises(NotImplementedError):
         f.fit_with_known_pose(torch.zeros(37, 72, device=dev), tv, tj, share_beta=True)
     with pytest.raises(ValueError):
@@ -502,3 +502,36 @@ def test_hipgraph_capture(B, model_root, golden, dev):
     eager = f.fit(tv_b, tj_b, num_iter=3)
     for k in ('pose_rotvecs', 'shape_betas', 'trans', 'orientations'):
         assert torch.equal(out[k], eager[k]), k
+
+
+@pytest.mark.parametrize('name', ['smpl', 'smplx'])
+def test_scale_goldens(name, model_root, golden, dev):
+    """fit(scale_target=True) / fit(scale_fit=True) (smplfit_fit_ex_f32, scale_mode) against the
+    reference's fixture, and the reference's own acceptance test (tests/test_fitter_common.py:118-240):
+    a body scaled by 1.1 is recovered with scale_corr ~ 1/1.1 resp. 1.1."""
+    from smplfitter_amd.pt import BodyFitter
+
+    g, ge = golden(name), golden(f'ext_{name}')
+    kind, md = util.load_md(model_root, name, g)
+    om, _ = util.make_oracle(md, kind)
+    m, f = get_model(model_root, name, g, dev)
+    kf = BodyFitter(m, enable_kid=True)
+    for case in util.SCALE_CASES:
+        if f'scale.{case}.trans' not in ge:
+            continue
+        kid_fit, tv, kw = util.scale_inputs(g, case)
+        kwt = {k: (t(v, dev) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+        o = to_np((kf if kid_fit else f).fit(t(tv, dev), requested_keys=['pose_rotvecs', 'scale_corr'], **kwt))
+        util.check_scale(om, name, case, o, ge, kid_fit)
+    if name != 'smpl':  # the reference's acceptance test is on SMPL
+        return
+    B = 300
+    tv, tj = make_targets(m, B, 31, dev)
+    r = f.fit(tv * 1.1, tj * 1.1, num_iter=3, beta_regularizer=0.0, scale_target=True)
+    back = m(r['pose_rotvecs'], r['shape_betas'], r['trans'])
+    err = (tv * 1.1 * r['scale_corr'][:, None, None] - back['vertices']).norm(dim=-1).mean().item()
+    assert err < 5e-3 and abs(r['scale_corr'].mean().item() - 1 / 1.1) < 0.05
+    r = f.fit(tv * 1.1, tj * 1.1, num_iter=5, beta_regularizer=0.0, scale_fit=True)
+    back = m(r['pose_rotvecs'], r['shape_betas'], r['trans'])
+    err = (tv * 1.1 - back['vertices'] * r['scale_corr'][:, None, None]).norm(dim=-1).mean().item()
+    assert err < 1e-2 and abs(r['scale_corr'].mean().item() - 1.1) < 0.05

@@ -147,3 +147,18 @@ def test_share_beta_goldens(name, model_root, golden):
         kid_fit, tv, kw = util.share_inputs(g, om, case)
         o = H.fit_warm(md, kind, tv, enable_kid=kid_fit, share_beta=True, **kw)
         util.check_share(om, name, case, o, ge, kid_fit)
+
+
+@pytest.mark.parametrize('name', ['smpl', 'smplx'])
+def test_scale_goldens(name, model_root, golden):
+    """scale_target / scale_fit through the shared stage code (extra vertex sums, scaled solve stage,
+    scaled refinement inputs) against the reference."""
+    g, ge = golden(name), golden(f'ext_{name}')
+    kind, md = util.load_md(model_root, name, g)
+    om, _ = util.make_oracle(md, kind)
+    for case in util.SCALE_CASES:
+        if f'scale.{case}.trans' not in ge:
+            continue
+        kid_fit, tv, kw = util.scale_inputs(g, case)
+        o = H.fit_warm(md, kind, tv, enable_kid=kid_fit, **kw)
+        util.check_scale(om, name, case, o, ge, kid_fit)
