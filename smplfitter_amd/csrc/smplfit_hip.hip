@@ -308,19 +308,23 @@ __global__ __launch_bounds__(256) void k_center_sort_partsum(DevModel m, const f
 // gather into part-sorted SoA order and the per-part sums against the template all run out of LDS.
 // (Real SMPL vertex order is not part-sorted: gathering 12-byte vertices straight from global
 // memory pulled ~8x the row through the fabric.)   part_seg_start: (J+1) first segment of each part.
-// dynamic LDS: 3V floats + 64.
+// dynamic LDS: 3 VL floats + 64, VL = vertices staged in LDS.  For SMPL the whole row (82.7 KB) would
+// allow one workgroup per CU only; staging the first VL = 6784 vertices (80 KB) and reading the last
+// 1.5 % of the row from L2 in the gather lets TWO workgroups share a CU, so one loads while the other
+// gathers / sums.
 // ------------------------------------------------------------------------------------------------
 template <bool WEIGHTED>
 __global__ __launch_bounds__(1024) void k_center_sort_partsum_lds(DevModel m, const float* __restrict__ tv,
                                                                  const float* __restrict__ tj,
                                                                  const float* __restrict__ vw,
-                                                                 Workspace ws) {
+                                                                 Workspace ws, int VL) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int V = m.V, J = m.J, Vp = m.Vp, n3 = 3 * V;
-  float* raw = smem;                       // [3V]
-  float* red = smem + ((n3 + 3) & ~3);     // [16][3] + mu[3]
+  const int V = m.V, J = m.J, Vp = m.Vp, n3 = 3 * V, nl = 3 * VL;
+  float* raw = smem;                       // [3 VL]
+  float* red = smem + ((nl + 3) & ~3);     // [16][3] + mu[3]
   const float* tvb = tv + (size_t)b * n3;
+  auto at = [&](int k) { return k < nl ? raw[k] : tvb[k]; };  // element k of the row
   // ---- coalesced row load (rows are 8-byte aligned: 3V*4 is a multiple of 8 when V is even)
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
   if ((n3 & 1) == 0) {
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(1024) void k_center_sort_partsum_lds(DevModel m, co
     float2* dst = reinterpret_cast<float2*>(raw);
     for (int k = tid; k < n3 / 2; k += 1024) {
       const float2 x = src[k];
-      dst[k] = x;
+      if (2 * k + 1 < nl) dst[k] = x;  // nl is even here (VL even or VL == V)
       const int r = (2 * k) % 3;  // coordinate of x.x; x.y is (r+1)%3
       s0 += (r == 0 ? x.x : 0.f) + (r == 2 ? x.y : 0.f);
       s1 += (r == 1 ? x.x : 0.f) + (r == 0 ? x.y : 0.f);
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(1024) void k_center_sort_partsum_lds(DevModel m, co
   } else {
     for (int k = tid; k < n3; k += 1024) {
       const float x = tvb[k];
-      raw[k] = x;
+      if (k < nl) raw[k] = x;
       const int r = k % 3;
       s0 += r == 0 ? x : 0.f;
       s1 += r == 1 ? x : 0.f;
@@ -379,9 +383,9 @@ __global__ __launch_bounds__(1024) void k_center_sort_partsum_lds(DevModel m, co
     const int o = m.perm[i];
     float t0 = 0.f, t1 = 0.f, t2 = 0.f, w = 0.f;
     if (o >= 0) {
-      t0 = raw[o * 3] - m0;
-      t1 = raw[o * 3 + 1] - m1;
-      t2 = raw[o * 3 + 2] - m2;
+      t0 = at(o * 3) - m0;
+      t1 = at(o * 3 + 1) - m1;
+      t2 = at(o * 3 + 2) - m2;
       if (WEIGHTED) w = vw[(size_t)b * V + o];
     }
     tvs[i] = t0;
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(1024) void k_center_sort_partsum_lds(DevModel m, co
       const int start = m.segments[s * 3], count = m.segments[s * 3 + 1];
       if (lane < count) {
         const int i = start + lane, o = m.perm[i];
-        const float t[3] = {raw[o * 3] - m0, raw[o * 3 + 1] - m1, raw[o * 3 + 2] - m2};
+        const float t[3] = {at(o * 3) - m0, at(o * 3 + 1) - m1, at(o * 3 + 2) - m2};
         const float a[3] = {m.dm[i], m.dm[Vp + i], m.dm[2 * Vp + i]};
         sf::partsum_vertex(t, a, WEIGHTED ? vw[(size_t)b * V + o] : 1.f, WEIGHTED, acc);
       }
@@ -1946,7 +1950,15 @@ void launch_lbs(const DevModel& d, const Workspace& ws, int B, bool weighted, in
 // K0 dispatch: LDS-staged form when the (V,3) row fits in LDS, gather form otherwise.
 void launch_center_sort(const DevModel& d, const float* tv, const float* tj, const float* vw,
                         const Workspace& ws, int B, hipStream_t st) {
-  const size_t lds_row = ((size_t)((3 * d.V + 3) & ~3) + 64) * 4;
+  // vertices staged in LDS: the whole row, or — when that leaves room for one workgroup per CU only but
+  // an 80 KB slice covers >= 15/16 of the row — the slice that lets two workgroups share the CU
+  int VL = d.V;
+  {
+    const int cap = ((80 * 1024 - 64 * 4) / 12) & ~1;
+    static const bool two = [] { const char* e = getenv("SMPLFIT_K0_TWO"); return !(e && e[0] == '0'); }();
+    if (two && d.V > cap && d.V - cap <= d.V / 16) VL = cap;
+  }
+  const size_t lds_row = ((size_t)((3 * VL + 3) & ~3) + 64) * 4;
   if (lds_row <= 160 * 1024) {
     static bool attr_set = false;  // dynamic LDS above 64 KB has to be opted into once per kernel
     if (!attr_set) {
@@ -1957,9 +1969,9 @@ void launch_center_sort(const DevModel& d, const float* tv, const float* tj, con
       attr_set = true;
     }
     if (vw)
-      hipLaunchKernelGGL((k_center_sort_partsum_lds<true>), dim3(B), dim3(1024), lds_row, st, d, tv, tj, vw, ws);
+      hipLaunchKernelGGL((k_center_sort_partsum_lds<true>), dim3(B), dim3(1024), lds_row, st, d, tv, tj, vw, ws, VL);
     else
-      hipLaunchKernelGGL((k_center_sort_partsum_lds<false>), dim3(B), dim3(1024), lds_row, st, d, tv, tj, vw, ws);
+      hipLaunchKernelGGL((k_center_sort_partsum_lds<false>), dim3(B), dim3(1024), lds_row, st, d, tv, tj, vw, ws, VL);
     return;
   }
   const size_t lds0 = ((size_t)4 * d.J * sf::kPsum + 20) * 4;
