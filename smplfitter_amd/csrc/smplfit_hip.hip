@@ -1,19 +1,25 @@
 // libsmplfit_hip.so — HIP kernels (gfx950 / CDNA4) and the C-ABI of include/smplfit.h.
 //
-// Kernel inventory (one launch each; grid = instances unless noted):
-//   k_center_sort_partsum  K0  mean-centre targets, re-order vertices by body part (SoA), part sums
-//                              against the template mesh           [HBM-bound streaming + wave sums]
+// Kernel inventory.  Wave-per-instance kernels (every configuration; grid = instances unless noted):
+//   k_center_sort_partsum(_lds)  K0  mean-centre targets, re-order vertices by body part (SoA), part
+//                              sums against the template mesh      [HBM-bound streaming + wave sums]
 //   k_joint_stage          K1  part rotations (SO(3) projections, swing-twist), shape prologue
 //                              (FK + beta-Jacobian, pose feature, joint normal equations)  [1 wave]
-//   k_posedirs_gemm        K2  v_posed = v_template + pose_feature . posedirs, fp32 MFMA 32x32x2,
-//                              128x128 LDS-tiled, grid = tiles                           [MFMA-bound]
+//   k_posedirs_gemm(_as)   K2  v_posed = v_template + pose_feature . posedirs, fp32 MFMA 32x32x2,
+//                              A-stationary (SMPL) or 128x128 LDS-tiled; plain or instance-innermost
+//                              output                                                    [MFMA-bound]
 //   k_shape_accum          K3  per-vertex blended rotation / position / shape Jacobian from LDS
 //                              joint block, 98 normal-equation sums per instance         [VALU-bound]
-//   k_shape_solve          K4  fp64 centring + 10x10 Cholesky + translation                 [1 wave]
+//   k_residual, k_pair_gram    the same block in pair-Gram form (SMPLFIT_SHAPE_FORM=pair)
+//   k_shape_solve          K4  fp64 centring + 10x10 Cholesky + translation (share_beta: + k_share_reduce;
+//                              scale options: k_scale_extras + k_shape_solve_scaled + k_scale_refs)
 //   k_lbs_partsum          K5  vertices at the solved shape (LBS) fused with the part sums of the
 //                              next rotation pass — the re-evaluated mesh never reaches HBM
 //   k_refine_epilogue      K6  dependent rotation refinement + relative rotations + log map [1 wave]
-//   k_forward_joint / k_lbs_forward   BodyModel.forward
+//   k_forward_joint, k_lbs_partsum<MODE 2>   BodyModel.forward;  k_scale_trans  known-shape alignment
+// Batch-major kernels (LANE = INSTANCE; the default vertex block where they apply, see bm_applies):
+//   k_transpose_targets, k_residual_bm, k_pair_gram_bm, k_gram_combine_bm, k_lbs_partsum_bm,
+//   k_psum_combine — grid = (vertex group | unit chunk) x instance blocks of 64.
 // Everything is enqueued on the caller's stream; no host synchronisation, no allocation.
 #include <hip/hip_runtime.h>
 
