@@ -535,3 +535,32 @@ def test_scale_goldens(name, model_root, golden, dev):
     back = m(r['pose_rotvecs'], r['shape_betas'], r['trans'])
     err = (tv * 1.1 - back['vertices'] * r['scale_corr'][:, None, None]).norm(dim=-1).mean().item()
     assert err < 1e-2 and abs(r['scale_corr'].mean().item() - 1.1) < 0.05
+
+
+def test_concurrent_calls_on_one_handle(model_root, golden, dev):
+    """Two host threads fitting through the SAME model handle at once (each on its own stream, own
+    workspace): the chunked fit's shared side streams / events are guarded, results equal serial ones."""
+    import threading
+
+    g = golden('smpl')
+    m, f = get_model(model_root, 'smpl', g, dev)
+    data = [make_targets(m, 1500, 40 + i, dev) for i in range(2)]
+    serial = [f.fit(tv, tj, num_iter=3) for tv, tj in data]
+    torch.cuda.synchronize()
+    out = [None, None]
+
+    def work(i):
+        s = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(s):
+            for _ in range(4):
+                out[i] = f.fit(data[i][0], data[i][1], num_iter=3)
+        s.synchronize()
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for i in range(2):
+        for k in ('pose_rotvecs', 'shape_betas', 'trans'):
+            assert torch.equal(out[i][k], serial[i][k]), (i, k)

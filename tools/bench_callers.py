@@ -1,0 +1,38 @@
+"""Throughput of the hot path's callers (BodyConverter.convert, fit_with_known_shape / pose) on one GPU."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from smplfitter_amd import synth
+from smplfitter_amd.pt import BodyConverter, BodyFitter, BodyModel
+
+dev = torch.device('cuda:0')
+root = synth.ensure_model_root(kinds=('smpl',))
+m = BodyModel('smpl', 'neutral', model_root=f'{root}/smpl', num_betas=10, device=dev)
+f = BodyFitter(m)
+B = 4096
+rs = np.random.RandomState(0)
+t = lambda a: torch.from_numpy(a.astype(np.float32)).to(dev)
+pose, betas, trans = t(rs.randn(B, 72) * 0.1), t(rs.randn(B, 10) * 0.5), t(rs.randn(B, 3))
+fw = m(pose, betas, trans)
+conv = BodyConverter(m, m)
+
+
+def timeit(name, fn, steps=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    print(f'{name}: {dt*1e3:.2f} ms per {B}, {B/dt:,.0f} /s', flush=True)
+
+
+timeit('BodyModel.forward', lambda: m(pose, betas, trans))
+timeit('BodyConverter.convert (num_iter=1)', lambda: conv.convert(pose, betas, trans, num_iter=1))
+timeit('BodyConverter.convert (num_iter=3)', lambda: conv.convert(pose, betas, trans, num_iter=3))
+timeit('fit joints omitted (num_iter=3)', lambda: f.fit(fw['vertices'], None, num_iter=3))
+timeit('fit weighted (num_iter=3)', lambda: f.fit(fw['vertices'], fw['joints'], vertex_weights=torch.ones(B, 6890, device=dev), joint_weights=torch.ones(B, 24, device=dev), num_iter=3))
+timeit('fit_with_known_shape (num_iter=3)', lambda: f.fit_with_known_shape(betas, fw['vertices'], fw['joints'], num_iter=3))
+timeit('fit_with_known_pose', lambda: f.fit_with_known_pose(pose, fw['vertices'], fw['joints']))
