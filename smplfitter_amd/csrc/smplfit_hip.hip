@@ -1966,14 +1966,17 @@ void launch_center_sort(const DevModel& d, const float* tv, const float* tj, con
   }
   const size_t lds_row = ((size_t)((3 * VL + 3) & ~3) + 64) * 4;
   if (lds_row <= 160 * 1024) {
-    static bool attr_set = false;  // dynamic LDS above 64 KB has to be opted into once per kernel
-    if (!attr_set) {
+    // dynamic LDS above 64 KB has to be opted into once per kernel (and per device: the attribute is
+    // set again whenever the current device changes; idempotent, so racing threads are harmless)
+    static std::once_flag once[16];
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    std::call_once(once[dev_id & 15], [] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_center_sort_partsum_lds<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_center_sort_partsum_lds<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
+    });
     if (vw)
       hipLaunchKernelGGL((k_center_sort_partsum_lds<true>), dim3(B), dim3(1024), lds_row, st, d, tv, tj, vw, ws, VL);
     else
