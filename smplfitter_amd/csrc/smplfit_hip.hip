@@ -71,6 +71,8 @@ struct DevModel {
   const int32_t* groups;  // (ngroups, kGroupRec): start, count, part, used, nq, joints[12]
   const float* brec;
   const float* pair_c1x;
+  // per joint: the resP rows (group * kResRec + 16 + 3 * slot) holding its residual moments
+  const int32_t *mb_start, *mb_row;
 };
 
 constexpr int kGroupRec = 5 + sf::kGroupJoints;
@@ -1834,12 +1836,8 @@ __global__ __launch_bounds__(256) void k_gram_combine_bm(DevModel m, Workspace w
   } else if (e < S + 3 + 3 * J) {  // residual moment of joint j, coordinate c
     const int j = (e - S - 3) / 3, c = (e - S - 3) % 3;
     float acc = 0.f;
-    for (int g = 0; g < m.ngroups; ++g) {
-      const int32_t* gr = m.groups + (size_t)g * kGroupRec;
-      const int nq = gr[4];
-      for (int q = 0; q < nq; ++q)
-        if (gr[5 + q] == j) acc += ws.resP[((size_t)g * kResRec + 16 + 3 * q + c) * Mp + b];
-    }
+    for (int k = m.mb_start[j]; k < m.mb_start[j + 1]; ++k)  // groups in table order
+      acc += ws.resP[((size_t)m.mb_row[k] + c) * Mp + b];
     ws.mbj[((size_t)b * J + j) * 3 + c] = acc;
   } else {  // Gramian entry: instance-independent part + the chunks of the pair kernel
     const int k = e - (S + 3 + 3 * J);
@@ -2451,6 +2449,15 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
       if (g.used) ++d.ngroups_used;  // used parts come first in slot order
     }
     up(gr, &d.groups);
+    std::vector<int32_t> mb_start(t.J + 1, 0), mb_row;
+    for (int j = 0; j < t.J; ++j) {
+      for (size_t g = 0; g < t.groups.size(); ++g)
+        for (int q = 0; q < t.groups[g].nq; ++q)
+          if (t.groups[g].joints[q] == j) mb_row.push_back((int32_t)(g * (16 + 3 * sf::kGroupJoints) + 16 + 3 * q));
+      mb_start[j + 1] = (int32_t)mb_row.size();
+    }
+    up(mb_start, &d.mb_start);
+    up(mb_row, &d.mb_row);
     up(t.brec, &d.brec);
     up(t.pair_c1x, &d.pair_c1x);
   }

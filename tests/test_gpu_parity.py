@@ -134,6 +134,8 @@ def test_fit_vs_oracle(name, B, model_root, golden, dev, vertex_path):
     tv, tj = make_targets(m, B, 42, dev, noise=0.005)
     o = to_np(f.fit(tv, tj, num_iter=3, beta_regularizer=1.0, requested_keys=['pose_rotvecs']))
     tvn, tjn = tv.cpu().numpy(), tj.cpu().numpy()
+    assert np.isfinite(tvn).all() and np.isfinite(tjn).all(), 'forward produced non-finite targets'
+    assert all(np.isfinite(v).all() for v in o.values()), 'fit produced non-finite results'
     r64 = of64.fit(tvn, tjn, num_iter=3, beta_regularizer=1.0)
     r32 = of32.fit(tvn, tjn, num_iter=3, beta_regularizer=1.0)
     assert util.vertex_l2(om64, o, r64) < 1e-4
