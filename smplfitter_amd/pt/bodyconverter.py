@@ -7,6 +7,7 @@ with a sparse barycentric matrix, and fitting the output model with the kid blen
 from __future__ import annotations
 
 import os
+import os.path as osp
 import pickle
 from typing import Optional
 
@@ -26,28 +27,24 @@ def load_vertex_converter_csr(path):
     return m[:, : m.shape[1] // 2]
 
 
+# official topology-transfer files under $DATA_ROOT/body_models, keyed by (V_in, V_out)
+_TRANSFER_FILES = {(6890, 10475): 'smpl2smplx_deftrafo_setup.pkl', (10475, 6890): 'smplx2smpl_deftrafo_setup.pkl'}
+
+
 class BodyConverter(nn.Module):
+    """Converts parameters between SMPL-family models (reference pt/bodyconverter.py:15-47)."""
+
     def __init__(self, body_model_in: BodyModel, body_model_out: BodyModel):
         super().__init__()
-        self.body_model_in = body_model_in
-        self.body_model_out = body_model_out
-        self.fitter = BodyFitter(self.body_model_out, enable_kid=True)
-        data_root = os.getenv('DATA_ROOT', '.')
-        vin, vout = body_model_in.num_vertices, body_model_out.num_vertices
-        if vin == 6890 and vout == 10475:
-            csr_path = f'{data_root}/body_models/smpl2smplx_deftrafo_setup.pkl'
-        elif vin == 10475 and vout == 6890:
-            csr_path = f'{data_root}/body_models/smplx2smpl_deftrafo_setup.pkl'
-        else:
-            csr_path = None
-        self.vertex_converter_csr: Optional[torch.Tensor]
-        if csr_path is not None:
-            m = load_vertex_converter_csr(csr_path)
-            csr = torch.sparse_csr_tensor(
-                torch.from_numpy(m.indptr), torch.from_numpy(m.indices), torch.from_numpy(m.data), m.shape)
+        self.body_model_in, self.body_model_out = body_model_in, body_model_out
+        self.fitter = BodyFitter(body_model_out, enable_kid=True)
+        fname = _TRANSFER_FILES.get((body_model_in.num_vertices, body_model_out.num_vertices))
+        self.vertex_converter_csr: Optional[torch.Tensor] = None  # same topology: identity
+        if fname is not None:
+            mat = load_vertex_converter_csr(osp.join(os.getenv('DATA_ROOT', '.'), 'body_models', fname))
+            csr = torch.sparse_csr_tensor(*(torch.from_numpy(a) for a in (mat.indptr, mat.indices, mat.data)),
+                                          mat.shape)
             self.vertex_converter_csr = nn.Buffer(csr.to(body_model_out.v_template.device))
-        else:
-            self.vertex_converter_csr = None
 
     def convert(
         self,

@@ -566,3 +566,21 @@ def test_concurrent_calls_on_one_handle(model_root, golden, dev):
     for i in range(2):
         for k in ('pose_rotvecs', 'shape_betas', 'trans'):
             assert torch.equal(out[i][k], serial[i][k]), (i, k)
+
+
+def test_cached_fit_fn(model_root, golden, dev):
+    """get_cached_fit_fn (reference pt/__init__.py:58-132): keyword list, leading batch shapes, caching."""
+    from smplfitter_amd.pt import get_cached_fit_fn
+
+    g = golden('smpl')
+    m, f = get_model(model_root, 'smpl', g, dev)
+    kw = dict(body_model_name='smpl', num_betas=10, num_iter=3, beta_regularizer=1.0, device='cuda:0',
+              model_root=f'{model_root}/smpl')
+    fn = get_cached_fit_fn(**kw)
+    assert get_cached_fit_fn(**kw) is fn
+    tv, tj = t(g['target_vertices'], dev), t(g['target_joints'], dev)
+    ref = f.fit(tv, tj, num_iter=3, beta_regularizer=1.0, requested_keys=['pose_rotvecs', 'shape_betas', 'trans'])
+    out = fn(tv.reshape(2, 2, -1, 3), tj.reshape(2, 2, -1, 3))
+    assert out['pose_rotvecs'].shape == (2, 2, 72) and out['orientations'].shape == (2, 2, 24, 3, 3)
+    for k in ('pose_rotvecs', 'shape_betas', 'trans'):
+        assert torch.equal(out[k].reshape(4, -1), ref[k])
