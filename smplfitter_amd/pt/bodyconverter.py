@@ -39,8 +39,10 @@ class BodyConverter(nn.Module):
         self.body_model_in, self.body_model_out = body_model_in, body_model_out
         self.fitter = BodyFitter(body_model_out, enable_kid=True)
         fname = _TRANSFER_FILES.get((body_model_in.num_vertices, body_model_out.num_vertices))
-        self.vertex_converter_csr: Optional[torch.Tensor] = None  # same topology: identity
-        if fname is not None:
+        self.vertex_converter_csr: Optional[torch.Tensor]
+        if fname is None:
+            self.vertex_converter_csr = None  # same topology: identity
+        else:
             mat = load_vertex_converter_csr(osp.join(os.getenv('DATA_ROOT', '.'), 'body_models', fname))
             csr = torch.sparse_csr_tensor(*(torch.from_numpy(a) for a in (mat.indptr, mat.indices, mat.data)),
                                           mat.shape)
