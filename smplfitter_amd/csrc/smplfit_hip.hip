@@ -1475,12 +1475,21 @@ __global__ __launch_bounds__(64 * kBW) __attribute__((amdgpu_waves_per_eu(4, 4))
     Raw rA, rB = fetch(min(v0 + 1, vl));
     auto step = [&](int v, const Raw& use, Raw& fill) {
       fill = fetch(min(v + 2, vl));
+      // this vertex's prepared values, then the preparation of the next one FIRST: its scalar loads
+      // are in flight while the LDS reads of the blend below are issued
+      const f2 cs01 = vs01, ct01 = t01;
+      const float cs2 = vs2, ct2 = t2;
+      const int o0 = off[0], o1 = off[1], o2 = off[2], o3 = off[3];
+      const float w0 = wq[0], w1 = wq[1], w2 = wq[2], w3 = wq[3];
+      prep(min(v + 1, vl), use, vs01, vs2, t01, t2, off, wq);
       // blend of the 4 joints: 6 register pairs
       f2 Q0 = mk2(0, 0), Q1 = Q0, Q2 = Q0, Q3 = Q0, Q4 = Q0, Q5 = Q0;
+      const int co[4] = {o0, o1, o2, o3};
+      const float cw[4] = {w0, w1, w2, w3};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float* src = smem + off[k];
-        const float w = wq[k];
+        const float* src = smem + co[k];
+        const float w = cw[k];
         Q0 += w * mk2(src[0], src[64]);
         Q1 += w * mk2(src[128], src[192]);
         Q2 += w * mk2(src[256], src[320]);
@@ -1488,9 +1497,6 @@ __global__ __launch_bounds__(64 * kBW) __attribute__((amdgpu_waves_per_eu(4, 4))
         Q4 += w * mk2(src[512], src[576]);
         Q5 += w * mk2(src[640], src[704]);
       }
-      const f2 cs01 = vs01, ct01 = t01;
-      const float cs2 = vs2, ct2 = t2;
-      prep(min(v + 1, vl), use, vs01, vs2, t01, t2, off, wq);
       // posed vertex (translation already folded into the staged jb)
       const f2 a01 = (Q0 * cs01.x + Q1 * cs01.y) + (Q2 * cs2 + Q5);
       const float a2 = (Q3.x * cs01.x + Q3.y * cs01.y) + (Q4.x * cs2 + Q4.y);
@@ -1605,12 +1611,16 @@ __global__ __launch_bounds__(64 * kBW) __attribute__((amdgpu_waves_per_eu(4, 4))
     slots_of(v0, off, wq);
     Raw rA = fetch(v0), rB = fetch(min(v0 + 1, vl));
     auto step = [&](int v, const Raw& cur, Raw& fill) {
+      // joint slots of the NEXT vertex first: the scalar loads fly while the LDS reads below issue
+      const int co[4] = {off[0], off[1], off[2], off[3]};
+      const float cw[4] = {wq[0], wq[1], wq[2], wq[3]};
+      slots_of(min(v + 1, vl), off, wq);
       // blend of the 4 joints: (R0,R3) (R1,R4) (R2,R5) (R6,R7) (R8,T0z) (T0x,T0y)
       f2 Q0 = mk2(0, 0), Q1 = Q0, Q2 = Q0, Q3 = Q0, Q4 = Q0, Q5 = Q0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float* src = smem + off[k];
-        const float w = wq[k];
+        const float* src = smem + co[k];
+        const float w = cw[k];
         Q0 += w * mk2(src[0], src[64]);
         Q1 += w * mk2(src[128], src[192]);
         Q2 += w * mk2(src[256], src[320]);
@@ -1619,7 +1629,6 @@ __global__ __launch_bounds__(64 * kBW) __attribute__((amdgpu_waves_per_eu(4, 4))
         Q5 += w * mk2(src[640], src[704]);
       }
       const float* rec = m.brec + (size_t)v * BS;  // shapedirs + dense weights of THIS vertex
-      slots_of(min(v + 1, vl), off, wq);           // joint slots of the next one
       // residual
       const f2 pos01 = (Q0 * cur.x0 + Q1 * cur.x1) + (Q2 * cur.x2 + Q5);
       const float pos2 = (Q3.x * cur.x0 + Q3.y * cur.x1) + (Q4.x * cur.x2 + Q4.y);
