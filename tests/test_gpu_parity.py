@@ -584,3 +584,47 @@ def test_cached_fit_fn(model_root, golden, dev):
     assert out['pose_rotvecs'].shape == (2, 2, 72) and out['orientations'].shape == (2, 2, 24, 3, 3)
     for k in ('pose_rotvecs', 'shape_betas', 'trans'):
         assert torch.equal(out[k].reshape(4, -1), ref[k])
+
+
+def test_cabi_error_paths(model_root, golden, dev):
+    """Status codes of the C-ABI for bad arguments (include/smplfit.h): -1 -> ValueError, -2 ->
+    NotImplementedError, -3 workspace -> RuntimeError; the error text comes from smplfit_last_error."""
+    import ctypes as C
+
+    from smplfitter_amd import _lib
+
+    g = golden('smpl')
+    m, f = get_model(model_root, 'smpl', g, dev)
+    lib, h = _lib.load(), m._native(dev)
+    B = 4
+    tv = t(g['target_vertices'], dev)
+    ws = torch.empty(h.workspace_bytes(B), dtype=torch.uint8, device=dev)
+    out = {k: torch.empty(s, device=dev) for k, s in dict(p=(B, 72), b=(B, 10), t=(B, 3), s=(B,)).items()}
+
+    def args(**over):
+        a = _lib.FitArgs(target_vertices=tv.data_ptr(), batch=B, num_iter=1, beta_regularizer=1.0,
+                         final_adjust_rots=1, pose_rotvecs=out['p'].data_ptr(), shape_betas=out['b'].data_ptr(),
+                         trans=out['t'].data_ptr(), workspace=ws.data_ptr(), workspace_bytes=ws.numel())
+        for k, v in over.items():
+            setattr(a, k, v)
+        return a
+
+    assert lib.smplfit_fit_ex_f32(h.ptr, C.byref(args())) == 0  # the baseline call is valid
+    for over, exc, text in (
+        (dict(scale_mode=3, scale_corr=out['s'].data_ptr()), ValueError, 'scale_mode'),
+        (dict(scale_mode=1), ValueError, 'scale_corr'),
+        (dict(scale_mode=1, scale_corr=out['s'].data_ptr(), share_beta=1), NotImplementedError, 'share_beta'),
+        (dict(num_iter=0), ValueError, 'num_iter'),
+        (dict(target_vertices=None), ValueError, 'null'),
+        (dict(initial_kid_factor=out['s'].data_ptr()), ValueError, 'kid'),
+        (dict(workspace_bytes=1024), RuntimeError, 'workspace'),
+        (dict(batch=0), ValueError, 'batch'),
+    ):
+        with pytest.raises(exc) as ei:
+            _lib.check(lib.smplfit_fit_ex_f32(h.ptr, C.byref(args(**over))))
+        assert text in str(ei.value), (over, str(ei.value))
+    with pytest.raises(ValueError):  # kid_factor on a handle without the kid column
+        _lib.check(lib.smplfit_fit_known_shape_f32(
+            h.ptr, out['b'].data_ptr(), 10, out['s'].data_ptr(), None, tv.data_ptr(), None, None, None, B, 1,
+            1, 0, out['p'].data_ptr(), out['t'].data_ptr(), None, None, None, ws.data_ptr(), ws.numel(), None))
+    torch.cuda.synchronize()
