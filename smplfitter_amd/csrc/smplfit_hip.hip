@@ -1378,7 +1378,10 @@ __host__ __device__ constexpr int brec_stride(int S, int KW) { return brec_d(S, 
 // reused as [kBW][16][64] for the wave combine.  Output: ws.psumP[g][16][Mp].
 // Per vertex: 24 ds_read2st64 + ~60 VALU (packed fp32); the vertex record is read with scalar loads
 // one vertex ahead (weights / slots) resp. right after its last use (shapedirs).
-constexpr int kBW = 8;  // waves per workgroup of the batch-major kernels (they share the staged joints)
+// waves per workgroup of the batch-major kernels (they share the staged joints).  4, not 8: one such
+// workgroup (1 wave per SIMD, ~120 VGPRs, 37 KB LDS) fits on a CU next to two GEMM workgroups of
+// another chunk, so the MFMA-bound GEMM and these VALU / LDS / HBM-bound passes really overlap
+constexpr int kBW = 4;
 
 template <int S, int KW>
 __global__ __launch_bounds__(64 * kBW) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lbs_partsum_bm(DevModel m, Workspace ws, int B, int Mp) {
@@ -2334,14 +2337,14 @@ int upload(smplfit_handle* h, const std::vector<T>& src, const T** dst) {
   return 0;
 }
 
-// Chunk plan of one fit call: large batches are split into chunks (default 2, SMPLFIT_CHUNKS=1..4) that run concurrently on
+// Chunk plan of one fit call: large batches are split into chunks (default 3, SMPLFIT_CHUNKS=1..4) that run concurrently on
 // the caller's stream and the handle's side streams, so that the MFMA-bound posedirs GEMM of one
 // chunk overlaps the VALU / HBM-bound vertex passes of the others (measured +5 % at B = 4096).
 // Chunk sizes are multiples of 128 (the GEMM's instance tile).
 int chunk_plan(int batch, int* sizes) {
   static const int want = [] {
     const char* e = getenv("SMPLFIT_CHUNKS");
-    int v = e ? atoi(e) : 2;  // measured at B = 4096: 1 chunk 1.04 M fits/s, 2: 1.10 M, 4: 1.09 M
+    int v = e ? atoi(e) : 3;  // measured at B = 4096 (batch-major kernels): 1 chunk 1.23 M fits/s, 2: 1.30 M, 3: 1.31 M, 4: 1.31 M
     return v < 1 ? 1 : (v > kMaxChunks ? kMaxChunks : v);
   }();
   int n = want;
