@@ -155,12 +155,18 @@ int smplfit_fit_warm_f32(const smplfit_handle* h, const float* target_vertices,
  *   share_beta != 0 -- BodyFitter.fit(share_beta=True): one shape (betas [+ kid]) for the whole batch;
  *   the regularised, centred normal equations of all instances are summed before the Cholesky solve
  *   (pt/lstsq.py:24-26 through lstsq_partial_share :32-90 with every unknown shared), every instance
- *   keeps its own translation.  The sum runs over the instances in order on one GPU; across GPUs it
- *   would be one all-reduce of (S*S + S) doubles per shape solve (not wired: smplfitter_amd.dist raises).
+ *   keeps its own translation.  The sum runs over the instances in order on one GPU; when the batch
+ *   is sharded over ranks (one process per GPU) `share_allreduce` completes it: after the local sum
+ *   of every shape solve the driver calls it once, on the calling thread, and it must ENQUEUE on
+ *   `hip_stream` an in-place sum all-reduce of `sums` (device memory, `count` = S*S + S doubles) over
+ *   the ranks -- e.g. ncclAllReduce(sums, sums, count, ncclDouble, ncclSum, comm, stream) -- and
+ *   return 0.  Every rank then solves the same summed system.  NULL = the batch is the whole batch.
  *   scale_mode -- BodyFitter.fit(scale_target=True) / (scale_fit=True): the LAST shape solve gets one more
  *   unknown, the refinement sees scaled targets resp. a scaled reference, the mean is added back scaled.
  *   shape_betas / kid_factor are returned as the reference returns them (undivided by the scale).
  * Zero-initialise the struct; fields left 0 / NULL mean "not given". */
+typedef int (*smplfit_share_allreduce_fn)(void* user, double* sums, int32_t count, void* hip_stream);
+
 typedef struct smplfit_fit_args {
   const float* target_vertices;      /* (B,V,3) */
   const float* target_joints;        /* (B,J,3) or NULL */
@@ -186,6 +192,8 @@ typedef struct smplfit_fit_args {
   void* workspace;
   size_t workspace_bytes;
   void* hip_stream;
+  smplfit_share_allreduce_fn share_allreduce; /* NULL, or the cross-rank sum of a sharded share_beta fit */
+  void* share_user;                  /* passed back to share_allreduce */
 } smplfit_fit_args;
 int smplfit_fit_ex_f32(const smplfit_handle* h, const smplfit_fit_args* args);
 
@@ -232,6 +240,45 @@ int smplfit_shape_solve_f32(const smplfit_handle* h, const float* glob_rotmats,
                             int add_mean, float* shape_betas, float* trans, float* kid_factor,
                             float* vertices_out, float* joints_out, void* workspace,
                             size_t workspace_bytes, void* hip_stream);
+
+/* The general form of smplfit_shape_solve_f32: fit_with_known_pose (pt/bodyfitter.py:552-653) with the
+ * options it hands to the shape solve (:623-638 -> _fit_shape_general :1104-1319).
+ *   beta_regularizer_reference (B,num_reference_betas) / kid_regularizer_reference (B) -- the values the
+ *   ridge pulls towards (:1224-1255); missing betas are 0; ignored with share_beta, as the all-shared
+ *   branch of the reference drops them (pt/lstsq.py:45-47)
+ *   share_beta, share_allreduce, share_user -- as smplfit_fit_args
+ *   scale_mode, scale_regularizer           -- one more unknown (1 scale_target, 2 scale_fit);
+ *   scale_corr (B) out; shape_betas / kid_factor as the reference returns them (undivided); with
+ *   add_mean the UNSCALED target mean is added to trans (:642-643).  No mesh outputs with a scale.
+ * Zero-initialise the struct; fields left 0 / NULL mean "not given". */
+typedef struct smplfit_shape_solve_args {
+  const float* glob_rotmats;         /* (B,J,3,3) */
+  const float* target_vertices;      /* (B,V,3) */
+  const float* target_joints;        /* (B,J,3) or NULL */
+  const float* vertex_weights;       /* (B,V) or NULL */
+  const float* joint_weights;        /* (B,J) or NULL */
+  int32_t batch;
+  float beta_regularizer, beta_regularizer2, kid_regularizer;
+  int32_t add_mean;
+  const float* beta_regularizer_reference; /* (B,num_reference_betas) or NULL */
+  int32_t num_reference_betas;
+  const float* kid_regularizer_reference;  /* (B) or NULL */
+  int32_t share_beta;
+  int32_t scale_mode;
+  float scale_regularizer;
+  float* shape_betas;                /* out (B,S) */
+  float* trans;                      /* out (B,3) */
+  float* kid_factor;                 /* out (B) or NULL */
+  float* scale_corr;                 /* out (B), required with scale_mode != 0 */
+  float* vertices_out;               /* out (B,V,3) or NULL */
+  float* joints_out;                 /* out (B,J,3) or NULL */
+  void* workspace;
+  size_t workspace_bytes;
+  void* hip_stream;
+  smplfit_share_allreduce_fn share_allreduce;
+  void* share_user;
+} smplfit_shape_solve_args;
+int smplfit_shape_solve_ex_f32(const smplfit_handle* h, const smplfit_shape_solve_args* args);
 
 /* Measurement hook (bench.py's roofline leg): launches ONE kernel of the fit `reps` times on
  * `hip_stream` between two HIP events recorded on that same stream and returns the average

@@ -392,7 +392,9 @@ class OracleFitter:
             lam = np.concatenate([lam, [float(scale_reg)]])
             if reg_ref is not None:
                 reg_ref = np.concatenate([np.asarray(reg_ref, np.float64), np.zeros((B, 1))], 1)
-        if reg_ref is not None:
+        if reg_ref is not None and not share_beta:
+            # the all-shared branch of lstsq_partial_share calls lstsq WITHOUT l2_regularizer_rhs
+            # (pt/lstsq.py:45-47): with share_beta the ridge pulls towards zero whatever the reference
             rhs_c = rhs_c + (lam[None] * np.asarray(reg_ref, np.float64))[..., None]
         if share_beta:
             # one shape for the whole batch: the regularised normal equations of all instances are summed
@@ -556,7 +558,13 @@ class OracleFitter:
     # -- shape + translation for a known pose (pt/bodyfitter.py:552-653) -----------------------------
     def fit_with_known_pose(self, pose_rotvecs, target_vertices, target_joints=None,
                             vertex_weights=None, joint_weights=None, beta_regularizer=1.0,
-                            beta_regularizer2=0.0, kid_regularizer=None):
+                            beta_regularizer2=0.0, scale_regularizer=0.0, kid_regularizer=None,
+                            share_beta=False, scale_target=False, scale_fit=False,
+                            beta_regularizer_reference=None, kid_regularizer_reference=None):
+        """One shape solve at the rotations of ``pose_rotvecs``; the options go straight into the solve
+        (:623-638) and the UNSCALED target mean is added back to the translation (:642-643)."""
+        if scale_target and scale_fit:
+            raise ValueError('Only one of estim_scale_target and estim_scale_fit can be True')
         m, dt, J, par = self.m, self.m.dtype, self.m.J, self.m.parents
         tv = np.asarray(target_vertices, dt)
         tj = None if target_joints is None else np.asarray(target_joints, dt)
@@ -574,10 +582,23 @@ class OracleFitter:
         for i in range(1, J):
             glob.append(glob[par[i]] @ rel[:, i])
         G = np.stack(glob, 1)
-        r = self.fit_shape(G, tv, tj, vw, jw, beta_regularizer, beta_regularizer2, kid_regularizer)
+        reg_ref = None
+        if beta_regularizer_reference is not None or kid_regularizer_reference is not None:
+            # references padded with zeros to all betas, the kid column appended (:1224-1246)
+            reg_ref = np.zeros((B, self.S_all), np.float64)
+            if beta_regularizer_reference is not None:
+                br = np.asarray(beta_regularizer_reference, np.float64)[:, :m.S]
+                reg_ref[:, :br.shape[1]] = br
+            if kid_regularizer_reference is not None and self.enable_kid:
+                reg_ref[:, m.S] = np.asarray(kid_regularizer_reference, np.float64).reshape(B)
+        r = self.fit_shape(G, tv, tj, vw, jw, beta_regularizer, beta_regularizer2, kid_regularizer,
+                           reg_ref=reg_ref, share_beta=share_beta,
+                           scale_mode=1 if scale_target else 2 if scale_fit else 0, scale_reg=scale_regularizer)
         out = dict(shape_betas=r['shape_betas'], trans=(r['trans'] + mean).astype(dt), orientations=G)
         if self.enable_kid:
             out['kid_factor'] = r['kid_factor']
+        if 'scale_corr' in r:
+            out['scale_corr'] = r['scale_corr']
         return out
 
     # -- pose + translation for a known shape (pt/bodyfitter.py:655-838) -----------------------------

@@ -33,11 +33,16 @@ EXPORTED_SYMBOLS = [
     'smplfit_create', 'smplfit_destroy', 'smplfit_last_error', 'smplfit_version',
     'smplfit_get_info', 'smplfit_get_table', 'smplfit_workspace_bytes', 'smplfit_fit_f32',
     'smplfit_forward_f32', 'smplfit_part_rotations_f32', 'smplfit_shape_solve_f32',
-    'smplfit_fit_known_shape_f32', 'smplfit_fit_warm_f32', 'smplfit_fit_ex_f32', 'smplfit_time_kernel_f32',
+    'smplfit_shape_solve_ex_f32', 'smplfit_fit_known_shape_f32', 'smplfit_fit_warm_f32', 'smplfit_fit_ex_f32',
+    'smplfit_time_kernel_f32',
 ]  # fmt: skip
 
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)
+
+
+# smplfit_share_allreduce_fn: int (*)(void* user, double* sums, int32_t count, void* hip_stream)
+ShareAllreduceFn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
 
 
 class FitArgs(C.Structure):
@@ -54,6 +59,23 @@ class FitArgs(C.Structure):
         ('orientations', C.c_void_p), ('relative_orientations', C.c_void_p), ('scale_corr', C.c_void_p),
         ('workspace', C.c_void_p),
         ('workspace_bytes', C.c_size_t), ('hip_stream', C.c_void_p),
+        ('share_allreduce', ShareAllreduceFn), ('share_user', C.c_void_p),
+    ]
+
+
+class ShapeSolveArgs(C.Structure):
+    """smplfit_shape_solve_args (include/smplfit.h)."""
+    _fields_ = [
+        ('glob_rotmats', C.c_void_p), ('target_vertices', C.c_void_p), ('target_joints', C.c_void_p),
+        ('vertex_weights', C.c_void_p), ('joint_weights', C.c_void_p), ('batch', C.c_int32),
+        ('beta_regularizer', C.c_float), ('beta_regularizer2', C.c_float), ('kid_regularizer', C.c_float),
+        ('add_mean', C.c_int32), ('beta_regularizer_reference', C.c_void_p),
+        ('num_reference_betas', C.c_int32), ('kid_regularizer_reference', C.c_void_p),
+        ('share_beta', C.c_int32), ('scale_mode', C.c_int32), ('scale_regularizer', C.c_float),
+        ('shape_betas', C.c_void_p), ('trans', C.c_void_p), ('kid_factor', C.c_void_p),
+        ('scale_corr', C.c_void_p), ('vertices_out', C.c_void_p), ('joints_out', C.c_void_p),
+        ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('hip_stream', C.c_void_p),
+        ('share_allreduce', ShareAllreduceFn), ('share_user', C.c_void_p),
     ]
 
 
@@ -136,6 +158,8 @@ def load():
     lib.smplfit_part_rotations_f32.restype = i32
     lib.smplfit_shape_solve_f32.argtypes = [vp, vp, vp, vp, vp, vp, i32, f32, f32, f32, i32, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.smplfit_shape_solve_f32.restype = i32
+    lib.smplfit_shape_solve_ex_f32.argtypes = [vp, C.POINTER(ShapeSolveArgs)]
+    lib.smplfit_shape_solve_ex_f32.restype = i32
     lib.smplfit_fit_known_shape_f32.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, sz, vp]
     lib.smplfit_fit_known_shape_f32.restype = i32
     lib.smplfit_time_kernel_f32.argtypes = [vp, i32, i32, i32, vp, sz, vp, C.POINTER(C.c_float)]

@@ -15,7 +15,8 @@ HERE = osp.dirname(osp.abspath(__file__))
 CSRC = osp.join(HERE, 'csrc')
 OUT = osp.join(HERE, 'libsmplfit_hip.so')
 SOURCES = ['smplfit_hip.hip', 'sf_tables.cpp']
-HEADERS = ['sf_math.h', 'sf_stages.h', 'sf_tables.h', '../../include/smplfit.h']
+HEADERS = ['sf_math.h', 'sf_stages.h', 'sf_tables.h', 'kernels_wave.inc', 'kernels_bm.inc',
+           '../../include/smplfit.h']
 
 
 def _hipcc():

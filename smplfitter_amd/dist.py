@@ -4,6 +4,10 @@ The fit of every instance is independent (reference: all reductions in ``BodyFit
 intra-instance unless ``share_beta``), so rank ``r`` of ``W`` fits a contiguous block of rows and the
 only communication is ONE all-gather of the packed result rows ``(B_local, 3J+S+3)`` —
 ``torch.distributed`` backend ``nccl`` (= RCCL over xGMI) on GPUs, ``gloo`` in the CPU tests.
+
+``share_beta`` is the one mode with an exchange step inside the fit (reference pt/lstsq.py:24-26: the
+normal equations are summed over the batch): every shape solve all-reduces the ``S*S + S`` doubles of
+the rank-local sums (``smplfit_fit_args.share_allreduce``), ``num_iter`` tiny collectives per fit.
 """
 
 from __future__ import annotations
@@ -38,6 +42,8 @@ def gather_rows(local_rows: torch.Tensor, total: int, group=None) -> torch.Tenso
     """All-gather ragged row blocks laid out by ``shard_range`` into one ``(total, C)`` tensor."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    if local_rows.is_cuda and dist.get_backend(group) == 'gloo':  # host collective: stage explicitly
+        return gather_rows(local_rows.cpu(), total, group).to(local_rows.device)
     sizes = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
     assert local_rows.shape[0] == sizes[rank]
     cols = local_rows.shape[1]
@@ -57,13 +63,15 @@ def fit_sharded(fit_fn, target_vertices: torch.Tensor, target_joints: Optional[t
                 num_joints: int, num_betas: int, group=None, **fit_kwargs) -> dict:
     """Every rank holds the FULL ``(B, V, 3)`` inputs (or generates them); each fits its block with
     ``fit_fn`` (e.g. ``BodyFitter.fit``) and all ranks receive the full result dict."""
-    if fit_kwargs.get('share_beta'):
-        # the shared shape couples every instance of the batch in each solve: across ranks that is one
-        # all-reduce of the (S*S + S) summed systems per shape solve, inside the fit -- not wired
-        raise NotImplementedError('share_beta fits are not sharded: run them on one GPU')
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     total = target_vertices.shape[0]
+    if fit_kwargs.get('share_beta'):
+        # the shared shape couples every instance of the batch in each solve: one all-reduce of the
+        # (S*S + S) summed systems per shape solve, issued from inside the fit
+        if total < world:
+            raise ValueError('a sharded share_beta fit needs at least one instance per rank')
+        fit_kwargs = dict(fit_kwargs, share_beta_group=group if group is not None else dist.group.WORLD)
     lo, hi = shard_range(total, rank, world)
     res = fit_fn(target_vertices[lo:hi], None if target_joints is None else target_joints[lo:hi],
                  **fit_kwargs)

@@ -17,6 +17,34 @@ from .. import _lib
 from .bodymodel import BodyModel, _ptr
 
 
+def _share_callback(ws: torch.Tensor, group):
+    """``smplfit_share_allreduce_fn`` for a ``share_beta`` batch sharded over ``group`` (a null callback
+    without one) and the list an exception raised inside it is parked in.  ``sums`` lies inside the
+    workspace tensor ``ws``; the collective is ordered after the kernels already enqueued on the current
+    stream (nccl = RCCL) or synchronous (gloo)."""
+    failure: list = []
+    if group is None:
+        return _lib.ShareAllreduceFn(), failure
+
+    def allreduce_sums(_user, sums_ptr, count, _stream):
+        try:
+            import torch.distributed as dist
+            off = sums_ptr - ws.data_ptr()
+            sums = ws.view(torch.uint8).reshape(-1)[off:off + 8 * count].view(torch.float64)
+            if dist.get_backend(group) == 'gloo':  # host collective: stage explicitly
+                staged = sums.cpu()
+                dist.all_reduce(staged, op=dist.ReduceOp.SUM, group=group)
+                sums.copy_(staged)
+            else:
+                dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+            return 0
+        except BaseException as e:  # never unwind through the C frames
+            failure.append(e)
+            return 1
+
+    return _lib.ShareAllreduceFn(allreduce_sums), failure
+
+
 class BodyFitter(nn.Module):
     """Fits SMPL-family parameters (pose, shape, translation) to target vertices (and joints).
 
@@ -32,22 +60,6 @@ class BodyFitter(nn.Module):
         self.n_betas = body_model.shapedirs.shape[2]
         self.enable_kid = enable_kid
         self.is_smpl_family = body_model.model_name.startswith('smpl')
-
-    def _check_options(self, share_beta, scale_target, scale_fit, beta_ref=None, kid_ref=None):
-        if scale_target and scale_fit:  # same check, same message as pt/bodyfitter.py:858-859
-            raise ValueError('Only one of estim_scale_target and estim_scale_fit can be True')
-        unsupported = []
-        if share_beta:
-            unsupported.append('share_beta (outside fit)')
-        if scale_target or scale_fit:
-            unsupported.append('scale_target/scale_fit (outside fit)')
-        if beta_ref is not None or kid_ref is not None:
-            unsupported.append('beta/kid_regularizer_reference')
-        if unsupported:
-            raise NotImplementedError(
-                'not implemented by the HIP fit kernels (reference falls back to _fit_shape_general, '
-                'pt/bodyfitter.py:1104-1319): ' + ', '.join(unsupported)
-            )
 
     def fit(
         self,
@@ -69,20 +81,30 @@ class BodyFitter(nn.Module):
         initial_kid_factor: Optional[torch.Tensor] = None,
         requested_keys: Optional[list[str]] = None,
         _workspace: Optional[torch.Tensor] = None,
+        share_beta_group=None,
     ) -> dict[str, torch.Tensor]:
         """Same arguments and returned keys as the reference's ``fit`` (pt/bodyfitter.py:283-549):
         ``shape_betas, trans, orientations, relative_orientations`` and ``pose_rotvecs`` when
         requested (default).  ``initial_pose_rotvecs / initial_shape_betas / initial_kid_factor``
-        warm-start the fit (``smplfit_fit_warm_f32``; reference :363-382)."""
+        warm-start the fit (``smplfit_fit_warm_f32``; reference :363-382).
+
+        ``share_beta_group`` (not in the reference): a ``torch.distributed`` process group over which
+        a ``share_beta`` batch is sharded, one block of instances per rank — the summed normal
+        equations of every shape solve are all-reduced over it, so all ranks get the shape of the
+        WHOLE batch (``smplfitter_amd.dist.fit_sharded`` passes it)."""
         if requested_keys is None:
             requested_keys = ['pose_rotvecs']
-        self._check_options(False, False, False)  # share_beta / scale options: smplfit_fit_ex_f32
         if scale_target and scale_fit:  # same check, same message as pt/bodyfitter.py:858-859
             raise ValueError('Only one of estim_scale_target and estim_scale_fit can be True')
         if share_beta and (scale_target or scale_fit):
             raise NotImplementedError('share_beta together with a scale unknown (partially shared solve, '
                                       'pt/lstsq.py:32-90) is not implemented')
         scale_mode = 1 if scale_target else 2 if scale_fit else 0
+        if share_beta_group is not None:
+            if not share_beta:
+                raise ValueError('share_beta_group needs share_beta=True')
+            if torch.compiler.is_compiling():
+                raise NotImplementedError('a sharded share_beta fit cannot be traced (collective inside the fit)')
         if initial_kid_factor is not None and not self.enable_kid:
             raise NotImplementedError(
                 'initial_kid_factor needs BodyFitter(enable_kid=True) on the HIP path')
@@ -106,7 +128,7 @@ class BodyFitter(nn.Module):
                                       num_iter, beta_regularizer, beta_regularizer2, kid_reg,
                                       final_adjust_rots, initial_pose_rotvecs, initial_shape_betas,
                                       initial_kid_factor, _workspace, share_beta, scale_mode,
-                                      scale_regularizer)
+                                      scale_regularizer, share_beta_group)
         # relative_orientations = parent^T @ global of the FINAL rotations (pt/bodyfitter.py:523-533);
         # returned always (the reference returns the pre-refinement ones when neither
         # 'relative_orientations' nor 'pose_rotvecs' is requested)
@@ -117,7 +139,7 @@ class BodyFitter(nn.Module):
     def _fit_direct(self, target_vertices, target_joints, vertex_weights, joint_weights, num_iter,
                     beta_regularizer, beta_regularizer2, kid_reg, final_adjust_rots,
                     initial_pose_rotvecs, initial_shape_betas, initial_kid_factor, _workspace,
-                    share_beta=False, scale_mode=0, scale_regularizer=0.0):
+                    share_beta=False, scale_mode=0, scale_regularizer=0.0, share_beta_group=None):
         """The C-ABI call behind ``fit`` (and behind the ``smplfitter_amd::fit`` operator): every result
         tensor, ``pose_rotvecs`` included."""
         bm = self.body_model
@@ -150,9 +172,12 @@ class BodyFitter(nn.Module):
         rel = torch.empty((B, J, 3, 3), dtype=torch.float32, device=device)
         kid = torch.empty((B,), dtype=torch.float32, device=device) if self.enable_kid else None
         scale = torch.empty((B,), dtype=torch.float32, device=device) if scale_mode else None
+        if B == 0 and share_beta_group is not None:
+            raise ValueError('every rank of a sharded share_beta fit needs at least one instance')
         if B > 0:
             h = bm._native(device, kid=self.enable_kid)
             ws = _workspace if _workspace is not None else bm._workspace(h, B, device)
+            callback, failure = _share_callback(ws, share_beta_group)
             with torch.cuda.device(device):
                 stream = torch.cuda.current_stream(device).cuda_stream
                 args = _lib.FitArgs(
@@ -171,8 +196,11 @@ class BodyFitter(nn.Module):
                     kid_factor=kid.data_ptr() if kid is not None else None, orientations=orient.data_ptr(),
                     relative_orientations=rel.data_ptr(),
                     scale_corr=scale.data_ptr() if scale is not None else None, workspace=ws.data_ptr(),
-                    workspace_bytes=ws.numel(), hip_stream=stream)
-                _lib.check(_lib.load().smplfit_fit_ex_f32(h.ptr, C.byref(args)))
+                    workspace_bytes=ws.numel(), hip_stream=stream, share_allreduce=callback)
+                rc = _lib.load().smplfit_fit_ex_f32(h.ptr, C.byref(args))
+                if failure:
+                    raise failure[0]
+                _lib.check(rc)
         result = dict(pose_rotvecs=pose, shape_betas=betas, trans=trans, orientations=orient,
                       relative_orientations=rel)
         if self.enable_kid:
@@ -199,12 +227,22 @@ class BodyFitter(nn.Module):
         beta_regularizer_reference: Optional[torch.Tensor] = None,
         kid_regularizer_reference: Optional[torch.Tensor] = None,
         requested_keys: Optional[list[str]] = None,
+        share_beta_group=None,
     ) -> dict[str, torch.Tensor]:
-        """Shape and translation for a known pose (reference pt/bodyfitter.py:552-653): global
-        rotations by forward kinematics of ``pose_rotvecs`` (the HIP forward kernel), then one shape
-        solve with the target mean added back."""
-        self._check_options(share_beta, scale_target, scale_fit, beta_regularizer_reference,
-                            kid_regularizer_reference)
+        """Shape and translation (and possibly scale) for a known pose (reference
+        pt/bodyfitter.py:552-653): global rotations by forward kinematics of ``pose_rotvecs`` (the HIP
+        forward kernel), then one shape solve (``smplfit_shape_solve_ex_f32``) with the target mean added
+        back.  ``share_beta`` ignores the ridge references, as the reference's all-shared solve does
+        (pt/lstsq.py:45-47).  ``share_beta_group``: as in :meth:`fit`."""
+        if scale_target and scale_fit:  # same check, same message as pt/bodyfitter.py:858-859
+            raise ValueError('Only one of estim_scale_target and estim_scale_fit can be True')
+        if share_beta and (scale_target or scale_fit):
+            raise NotImplementedError('share_beta together with a scale unknown (partially shared solve, '
+                                      'pt/lstsq.py:32-90) is not implemented')
+        if share_beta_group is not None and not share_beta:
+            raise ValueError('share_beta_group needs share_beta=True')
+        if kid_regularizer_reference is not None and not self.enable_kid:
+            kid_regularizer_reference = None  # the reference only reads it with enable_kid (:1235-1246)
         bm = self.body_model
         B = target_vertices.shape[0]
         pose = pose_rotvecs.reshape(B, bm.num_joints * 3)
@@ -212,7 +250,10 @@ class BodyFitter(nn.Module):
         kid_reg = float(beta_regularizer if kid_regularizer is None else kid_regularizer)
         r = self._shape_solve(G, target_vertices, target_joints, vertex_weights, joint_weights,
                               beta_regularizer, beta_regularizer2, kid_regularizer=kid_reg,
-                              add_mean=True, want_mesh=False)
+                              add_mean=True, want_mesh=False, share_beta=share_beta,
+                              scale_mode=1 if scale_target else 2 if scale_fit else 0,
+                              scale_regularizer=scale_regularizer, beta_ref=beta_regularizer_reference,
+                              kid_ref=kid_regularizer_reference, share_beta_group=share_beta_group)
         parents = bm.kintree_parents_tensor[1:].to(G.device)
         parent_glob = torch.cat(
             [torch.eye(3, device=G.device).expand(B, 1, 3, 3), G.index_select(1, parents)], dim=1)
@@ -220,6 +261,8 @@ class BodyFitter(nn.Module):
                    relative_orientations=parent_glob.transpose(-1, -2) @ G)
         if self.enable_kid:
             out['kid_factor'] = r['kid_factor']
+        if 'scale_corr' in r:
+            out['scale_corr'] = r['scale_corr']
         return out
 
     def fit_with_known_shape(
@@ -309,7 +352,8 @@ class BodyFitter(nn.Module):
 
     def _shape_solve(self, glob_rotmats, target_vertices, target_joints=None, vertex_weights=None,
                      joint_weights=None, beta_regularizer=1.0, beta_regularizer2=0.0,
-                     kid_regularizer=None, add_mean=False, want_mesh=True):
+                     kid_regularizer=None, add_mean=False, want_mesh=True, share_beta=False, scale_mode=0,
+                     scale_regularizer=0.0, beta_ref=None, kid_ref=None, share_beta_group=None):
         """One shape solve for given global rotations; targets are centred internally and, unless
         ``add_mean``, the returned trans / vertices / joints live in the centred frame."""
         bm = self.body_model
@@ -318,23 +362,44 @@ class BodyFitter(nn.Module):
         G, tv, tj = prep(glob_rotmats), prep(target_vertices), prep(target_joints)
         vw, jw = prep(vertex_weights), prep(joint_weights)
         B, J, V, S = tv.shape[0], bm.num_joints, bm.num_vertices, self.n_betas
+        bref = None if beta_ref is None else prep(beta_ref)[:, :S].contiguous()
+        kref = None
+        if kid_ref is not None:
+            kref = torch.as_tensor(kid_ref, dtype=torch.float32, device=device).reshape(-1)
+            kref = kref.expand(B).contiguous() if kref.numel() == 1 else kref.contiguous()
         betas = torch.empty((B, S), dtype=torch.float32, device=device)
         trans = torch.empty((B, 3), dtype=torch.float32, device=device)
         verts = torch.empty((B, V, 3), dtype=torch.float32, device=device) if want_mesh else None
         joints = torch.empty((B, J, 3), dtype=torch.float32, device=device) if want_mesh else None
         kid = torch.empty((B,), dtype=torch.float32, device=device) if self.enable_kid else None
+        scale = torch.empty((B,), dtype=torch.float32, device=device) if scale_mode else None
         kid_reg = float(beta_regularizer if kid_regularizer is None else kid_regularizer)
         h = bm._native(device, kid=self.enable_kid)
         ws = bm._workspace(h, B, device)
+        callback, failure = _share_callback(ws, share_beta_group)
+        p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
-            _lib.check(_lib.load().smplfit_shape_solve_f32(
-                h.ptr, _ptr(G), _ptr(tv), _ptr(tj), _ptr(vw), _ptr(jw), B, float(beta_regularizer),
-                float(beta_regularizer2), kid_reg, int(bool(add_mean)), _ptr(betas), _ptr(trans),
-                _ptr(kid), _ptr(verts), _ptr(joints), _ptr(ws), ws.numel(), C.c_void_p(stream)))
+            args = _lib.ShapeSolveArgs(
+                glob_rotmats=p(G), target_vertices=p(tv), target_joints=p(tj), vertex_weights=p(vw),
+                joint_weights=p(jw), batch=B, beta_regularizer=float(beta_regularizer),
+                beta_regularizer2=float(beta_regularizer2), kid_regularizer=kid_reg,
+                add_mean=int(bool(add_mean)), beta_regularizer_reference=p(bref),
+                num_reference_betas=0 if bref is None else bref.shape[1], kid_regularizer_reference=p(kref),
+                share_beta=int(bool(share_beta)), scale_mode=int(scale_mode),
+                scale_regularizer=float(scale_regularizer), shape_betas=p(betas), trans=p(trans),
+                kid_factor=p(kid), scale_corr=p(scale), vertices_out=p(verts), joints_out=p(joints),
+                workspace=ws.data_ptr(), workspace_bytes=ws.numel(), hip_stream=stream,
+                share_allreduce=callback)
+            rc = _lib.load().smplfit_shape_solve_ex_f32(h.ptr, C.byref(args))
+            if failure:
+                raise failure[0]
+            _lib.check(rc)
         out = dict(shape_betas=betas, trans=trans)
         if want_mesh:
             out.update(vertices=verts, joints=joints)
         if self.enable_kid:
             out['kid_factor'] = kid
+        if scale_mode:
+            out['scale_corr'] = scale
         return out

@@ -225,6 +225,8 @@ struct Emu {
   }
 
   bool share_beta = false;  // one shape for the batch: assemble, sum in instance order, solve the sum
+  smplfit_share_allreduce_fn share_allreduce = nullptr;  // as smplfit_fit_args.share_allreduce, host memory
+  void* share_user = nullptr;
   void k4(float reg, float reg2, float kid_reg) {
     const int J = t.J, NE1 = sf::ne_size(S) + 1, NC = S * S + S;
     HostCtx cx;
@@ -235,7 +237,8 @@ struct Emu {
                       use_pair_gram ? mbj.data() + (size_t)b * J * 3 : nullptr, reg, reg2, kid_reg,
                       beta.data() + (size_t)b * S, trans.data() + (size_t)b * 3,
                       rjoints.data() + (size_t)b * J * 3, jb.data() + (size_t)b * J * 4,
-                      regref.empty() ? nullptr : regref.data() + (size_t)b * S, mode, c);
+                      // the all-shared solve ignores the ridge reference (pt/lstsq.py:45-47)
+                      (regref.empty() || mode != 0) ? nullptr : regref.data() + (size_t)b * S, mode, c);
     };
     if (!share_beta) {
       for (int b = 0; b < B; ++b) stage(b, 0, nullptr);
@@ -250,6 +253,7 @@ struct Emu {
       for (; b < B; ++b) a[0] += cen[(size_t)b * NC + e];
       cen[(size_t)B * NC + e] = (a[0] + a[1]) + (a[2] + a[3]);
     }
+    if (share_allreduce) share_allreduce(share_user, cen.data() + (size_t)B * NC, NC, nullptr);
     for (int b = 0; b < B; ++b) stage(b, 2, cen.data() + (size_t)B * NC);
   }
 
@@ -292,6 +296,8 @@ struct Warm {  // warm start of fit (mirrors FitOptions::init_* in smplfit_hip.h
   int nb = 0;
   const float* kid = nullptr;
   int share_beta = 0;
+  smplfit_share_allreduce_fn share_allreduce = nullptr;
+  void* share_user = nullptr;
   int scale_mode = 0;  // 1 scale_target, 2 scale_fit
   float scale_reg = 0.f;
   float* scale_out = nullptr;
@@ -305,6 +311,8 @@ int fit_impl(const sf::HostTables& t, const float* tv, const float* tj, const fl
   const Warm w = g_warm;
   Emu<S, KW> e(t, B);
   e.share_beta = g_warm.share_beta != 0;
+  e.share_allreduce = g_warm.share_allreduce;
+  e.share_user = g_warm.share_user;
   const bool joints = tj != nullptr;
   const bool eff_v = joints ? (vw && jw) : (vw != nullptr);
   const bool eff_j = joints && vw && jw;
@@ -576,12 +584,22 @@ int hostemu_fit(const smplfit_model_desc* d, const float* tv, const float* tj, c
   return -2;
 }
 
+// the cross-rank sum of a sharded share_beta fit for the NEXT hostemu_fit_warm calls of this thread
+thread_local smplfit_share_allreduce_fn g_share_allreduce = nullptr;
+thread_local void* g_share_user = nullptr;
+void hostemu_set_share_allreduce(smplfit_share_allreduce_fn fn, void* user) {
+  g_share_allreduce = fn;
+  g_share_user = user;
+}
+
 int hostemu_fit_warm(const smplfit_model_desc* d, const float* tv, const float* tj, const float* vw,
                      const float* jw, int B, int num_iter, float reg, float reg2, float kid_reg,
                      int final_adjust, const float* init_pose, const float* init_betas, int init_nb,
                      const float* init_kid, int share_beta, int scale_mode, float scale_reg,
                      float* scale_out, float* pose, float* betas, float* trans, float* kid, float* orient) {
   g_warm.share_beta = share_beta;
+  g_warm.share_allreduce = share_beta ? g_share_allreduce : nullptr;
+  g_warm.share_user = g_share_user;
   g_warm.scale_mode = scale_mode;
   g_warm.scale_reg = scale_reg;
   g_warm.scale_out = scale_out;

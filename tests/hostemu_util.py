@@ -40,6 +40,8 @@ def load():
     lib.hostemu_forward.restype = i32
     lib.hostemu_fit_warm.argtypes = [C.POINTER(_lib.ModelDesc), vp, vp, vp, vp, i32, i32, f32, f32, f32, i32, vp, vp, i32, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp]
     lib.hostemu_fit_warm.restype = i32
+    lib.hostemu_set_share_allreduce.argtypes = [_lib.ShareAllreduceFn, vp]
+    lib.hostemu_set_share_allreduce.restype = None
     lib.hostemu_fit_known_shape.argtypes = [C.POINTER(_lib.ModelDesc), vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.hostemu_fit_known_shape.restype = i32
     lib.hostemu_last_error.restype = C.c_char_p
@@ -136,11 +138,20 @@ def fit_warm(md, kind, tv, target_joints=None, vertex_weights=None, joint_weight
              beta_regularizer=1.0, beta_regularizer2=0.0, final_adjust_rots=True, enable_kid=False,
              kid_regularizer=None, initial_pose_rotvecs=None, initial_shape_betas=None,
              initial_kid_factor=None, share_beta=False, scale_target=False, scale_fit=False,
-             scale_regularizer=0.0):
+             scale_regularizer=0.0, share_allreduce=None):
+    """``share_allreduce(sums: float64 ndarray)`` sums the array in place over the ranks of a sharded
+    ``share_beta`` fit (the host-memory counterpart of ``smplfit_fit_args.share_allreduce``)."""
     lib = load()
     desc, keep = desc_from_md(md, kind, enable_kid)
     if kid_regularizer is None:
         kid_regularizer = beta_regularizer
+
+    def _cb(_user, ptr, count, _stream):
+        share_allreduce(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(count,)))
+        return 0
+
+    cb = _lib.ShareAllreduceFn(_cb) if share_allreduce is not None else _lib.ShareAllreduceFn()
+    lib.hostemu_set_share_allreduce(cb, None)
     f = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)  # noqa: E731
     tv, tj, vw, jw = f(tv), f(target_joints), f(vertex_weights), f(joint_weights)
     ip, ib, ik = f(initial_pose_rotvecs), f(initial_shape_betas), f(initial_kid_factor)
@@ -157,6 +168,7 @@ def fit_warm(md, kind, tv, target_joints=None, vertex_weights=None, joint_weight
                               0 if ib is None else ib.shape[1], _p(ik), int(share_beta), scale_mode, scale_regularizer,
                               _p(scale), _p(pose), _p(betas), _p(trans),
                               _p(kid), _p(orient))
+    lib.hostemu_set_share_allreduce(_lib.ShareAllreduceFn(), None)
     if rc != 0:
         raise RuntimeError(lib.hostemu_last_error().decode())
     out = dict(pose_rotvecs=pose, shape_betas=betas, trans=trans, orientations=orient)

@@ -1,6 +1,8 @@
-"""World-size-2 gloo test of the batch sharding + result gather (the N > 1 path of bench.py /
-smplfitter_amd.dist).  The per-rank fit is stood in by the CPU oracle on a tiny batch so that the
-test runs without a GPU; the distributed plumbing under test is identical for nccl/RCCL."""
+"""World-size-2 gloo tests of the batch sharding + result gather (the N > 1 path of bench.py /
+smplfitter_amd.dist) and of the one exchange step the path has: the all-reduce of the summed normal
+equations in a sharded ``share_beta`` fit.  The per-rank fit is stood in by a table lookup resp. the
+host-compiled stage code so that the tests run without a GPU; the distributed plumbing under test
+(``fit_sharded``, the ``share_allreduce`` callback contract) is identical for nccl/RCCL."""
 
 import os
 import sys
@@ -49,6 +51,59 @@ def test_shard_and_gather_world2(total, tmp_path):
     r1 = torch.load(tmp_path / 'r1.pt')
     assert r0['ok'] and r1['ok']
     assert r0['lo'] == 0 and r0['hi'] == r1['lo'] and r1['hi'] == total
+
+
+def _share_worker(rank, world, port, root, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import hostemu_util as H
+    import util
+    from smplfitter_amd import dist as sd
+
+    g = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_smpl.npz'), allow_pickle=False))
+    kind, md = util.load_md(root, 'smpl', g)
+    om, _ = util.make_oracle(md, kind)
+    _, tv, kw = util.share_inputs(g, om, 'a')
+    tj = kw.pop('target_joints')
+    calls = []
+
+    def fit_fn(v, j, share_beta_group=None, **k):  # BodyFitter.fit's contract, host-compiled stages
+        def allreduce(sums):
+            t = torch.from_numpy(sums)  # shares memory with the C buffer
+            dist.all_reduce(t, group=share_beta_group)
+            calls.append(1)
+
+        o = H.fit_warm(md, kind, v.numpy(), target_joints=None if j is None else j.numpy(),
+                       share_allreduce=allreduce if share_beta_group is not None else None, **k)
+        return {n: torch.from_numpy(a) for n, a in o.items()}
+
+    out = sd.fit_sharded(fit_fn, torch.from_numpy(tv), torch.from_numpy(tj), md.num_joints, 10,
+                         share_beta=True, **kw)
+    if rank == 0:
+        whole = H.fit_warm(md, kind, tv, target_joints=tj, share_beta=True, **kw)
+        np.savez(os.path.join(tmp, 'share.npz'), ncalls=len(calls), num_iter=kw['num_iter'],
+                 **{f'sharded_{n}': a.numpy() for n, a in out.items()},
+                 **{f'whole_{n}': whole[n] for n in ('pose_rotvecs', 'shape_betas', 'trans')})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_share_beta_sharded_world2(model_root, tmp_path):
+    """share_beta over a batch split between two ranks: each rank sums its own systems, the callback
+    all-reduces them, both solve the same sum — the shape of the whole batch, as one rank computes it
+    (the fp64 sums only differ in their order)."""
+    port = 29500 + (os.getpid() % 1000) + 17
+    mp.spawn(_share_worker, args=(2, port, model_root, str(tmp_path)), nprocs=2, join=True)
+    r = np.load(tmp_path / 'share.npz')
+    assert int(r['ncalls']) == int(r['num_iter'])  # one collective per shape solve
+    betas = r['sharded_shape_betas']
+    assert np.abs(betas - betas[:1]).max() == 0  # one shape on every rank's rows
+    for n, tol in (('shape_betas', 2e-6), ('trans', 2e-6), ('pose_rotvecs', 2e-5)):
+        assert np.abs(r[f'sharded_{n}'] - r[f'whole_{n}']).max() < tol, n
 
 
 def test_shard_range_covers():

@@ -6,6 +6,9 @@ forward(ours) and forward(reference) <= 1e-4 m; shape_betas <= 3e-4 (fp32 Gramia
 reference itself is 1e-4-class on the SMPL-X fixture), trans <= 1e-5; pose_rotvecs sits at the
 reference's own fp32 noise floor (3e-4 typical, more on thin parts) and is bounded loosely."""
 
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -13,6 +16,7 @@ import torch
 import util
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope='module')
@@ -164,7 +168,9 @@ def test_edge_batches(model_root, golden, dev):
     with pytest.raises(NotImplementedError):
         f.fit(tv, tj, scale_fit=True, share_beta=True)
     with pytest.raises(NotImplementedError):
-        f.fit_with_known_pose(torch.zeros(37, 72, device=dev), tv, tj, share_beta=True)
+        f.fit_with_known_pose(torch.zeros(37, 72, device=dev), tv, tj, share_beta=True, scale_target=True)
+    with pytest.raises(ValueError):
+        f.fit_with_known_pose(torch.zeros(37, 72, device=dev), tv, tj, scale_target=True, scale_fit=True)
     with pytest.raises(ValueError):
         m(pose_rotvecs=torch.zeros(1, 72, device=dev), glob_rotmats=torch.zeros(1, 24, 3, 3, device=dev))
     with pytest.raises(TypeError):
@@ -464,6 +470,12 @@ def test_share_beta_goldens(name, model_root, golden, dev, vertex_path):
         kwt = {k: (t(v, dev) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
         o = to_np((kf if kid_fit else f).fit(t(tv, dev), share_beta=True, requested_keys=['pose_rotvecs'], **kwt))
         util.check_share(om, name, case, o, ge, kid_fit)
+    gk = golden(f'kp_{name}')
+    if 'sharewarm.a.trans' in gk:  # share_beta + warm start: the ridge reference is dropped (pt/lstsq.py:45-47)
+        _, tv, kw = util.warm_inputs(g, 'a')
+        kwt = {k: (t(v, dev) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+        o = to_np(f.fit(t(tv, dev), share_beta=True, requested_keys=['pose_rotvecs'], **kwt))
+        util.check_share(om, name, 'a', o, gk, False, prefix='sharewarm')
     # a large batch takes the same (unchunked) path: all rows of shape_betas identical
     B = 1500
     rs = np.random.RandomState(8)
@@ -475,6 +487,101 @@ def test_share_beta_goldens(name, model_root, golden, dev, vertex_path):
     assert (r['shape_betas'] - r['shape_betas'][:1]).abs().max().item() == 0
     back = m(r['pose_rotvecs'], r['shape_betas'], r['trans'])
     assert (back['vertices'] - fw['vertices']).norm(dim=-1).mean().item() < 5e-3
+
+
+@pytest.mark.parametrize('name', ['smpl', 'smplx'])
+def test_known_pose_option_goldens(name, model_root, golden, dev):
+    """fit_with_known_pose with share_beta / scale_target / scale_fit / ridge references
+    (smplfit_shape_solve_ex_f32) against the reference's fixture, and against the oracle at B = 300."""
+    from smplfitter_amd.pt import BodyFitter
+
+    g, gk = golden(name), golden(f'kp_{name}')
+    kind, md = util.load_md(model_root, name, g)
+    m, f = get_model(model_root, name, g, dev)
+    fitters = {False: f, True: BodyFitter(m, enable_kid=True)}
+    n = 0
+    for case in util.KNOWN_POSE_CASES:
+        if f'knownpose.{case}.trans' not in gk:
+            continue
+        kid_fit, pose, tv, kw = util.known_pose_inputs(g, case)
+        kwt = {k: (t(v, dev) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+        o = to_np(fitters[kid_fit].fit_with_known_pose(t(pose, dev), t(tv, dev), **kwt))
+        util.check_known_pose(name, case, o, gk, kid_fit)
+        n += 1
+    assert n >= 3
+    if name != 'smpl':
+        return
+    om, _ = util.make_oracle(md, kind, np.float64)
+    okf = util.O.OracleFitter(om, enable_kid=True)
+    B, J = 300, md.num_joints
+    rs = np.random.RandomState(31)
+    pose = (rs.randn(B, 3 * J) * 0.1).astype(np.float32)
+    betas = (rs.randn(B, 10) * 0.5).astype(np.float32)
+    fw = om.forward(pose, betas, rs.randn(B, 3).astype(np.float32))
+    tv = (fw['vertices'] * 0.93 + rs.randn(B, md.num_vertices, 3) * 0.002).astype(np.float32)
+    tj = (fw['joints'] * 0.93).astype(np.float32)
+    kw = dict(beta_regularizer=1.0, scale_regularizer=0.2, scale_fit=True, kid_regularizer=3.0,
+              beta_regularizer_reference=(betas + 0.1).astype(np.float32),
+              kid_regularizer_reference=np.full(B, 0.05, np.float32))
+    ref = okf.fit_with_known_pose(pose, tv, tj, **kw)
+    kwt = {k: (t(v, dev) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+    o = to_np(fitters[True].fit_with_known_pose(t(pose, dev), t(tv, dev), t(tj, dev), **kwt))
+    assert np.abs(o['scale_corr'] - ref['scale_corr']).max() < 2e-5
+    assert np.abs(o['shape_betas'] - ref['shape_betas']).max() < 3e-4
+    assert np.abs(o['kid_factor'] - ref['kid_factor']).max() < 3e-4
+    assert np.abs(o['trans'] - ref['trans']).max() < 2e-5
+
+
+def _share_rank(rank, world, backend, port, root, tmp):
+    """One rank of a sharded share_beta fit; every rank drives cuda:0 (the box has one GPU)."""
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        from smplfitter_amd import dist as sd
+
+        dev = torch.device('cuda:0')
+        g = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_smpl.npz'), allow_pickle=False))
+        m, f = get_model(root, 'smpl', g, dev)
+        B, J = 96, m.num_joints
+        rs = np.random.RandomState(12)
+        fw = m(t((rs.randn(B, 3 * J) * 0.1).astype(np.float32), dev),
+               t(np.repeat((rs.randn(1, 10) * 0.5).astype(np.float32), B, 0), dev),
+               t(rs.randn(B, 3).astype(np.float32), dev))
+        tv = fw['vertices'] + t((rs.randn(B, m.num_vertices, 3) * 0.003).astype(np.float32), dev)
+        kw = dict(num_iter=3, beta_regularizer=0.5, share_beta=True)
+        out = sd.fit_sharded(f.fit, tv, fw['joints'], J, 10, **kw)
+        if rank == 0:
+            whole = f.fit(tv, fw['joints'], **kw)
+            np.savez(os.path.join(tmp, 'share.npz'),
+                     **{f'sharded_{n}': a.cpu().numpy() for n, a in out.items()},
+                     **{f'whole_{n}': whole[n].cpu().numpy() for n in ('pose_rotvecs', 'shape_betas', 'trans')})
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,backend', [(1, 'nccl'), (2, 'gloo')])
+def test_share_beta_sharded(world, backend, model_root, tmp_path):
+    """fit_sharded(share_beta=True): the rank-local sums of every shape solve are all-reduced from inside
+    the fit (smplfit_fit_args.share_allreduce).  world 1 / nccl: the RCCL collective ordered on the fit's
+    stream, result identical to the plain call; world 2 / gloo (both ranks on the one GPU of the box):
+    the shape of the whole batch on every rank, equal to the one-rank fit up to the order of the fp64
+    sums."""
+    import torch.multiprocessing as mp
+
+    port = 29500 + (os.getpid() % 1000) + 31 + world
+    mp.spawn(_share_rank, args=(world, backend, port, model_root, str(tmp_path)), nprocs=world, join=True)
+    r = np.load(tmp_path / 'share.npz')
+    betas = r['sharded_shape_betas']
+    assert np.abs(betas - betas[:1]).max() == 0
+    for n, tol in (('shape_betas', 2e-6), ('trans', 2e-6), ('pose_rotvecs', 2e-5)):
+        d = np.abs(r[f'sharded_{n}'] - r[f'whole_{n}']).max()
+        assert d == 0 if world == 1 else d < tol, (n, d)
 
 
 @pytest.mark.parametrize('B', [48, 2304])

@@ -147,6 +147,11 @@ def test_share_beta_goldens(name, model_root, golden):
         kid_fit, tv, kw = util.share_inputs(g, om, case)
         o = H.fit_warm(md, kind, tv, enable_kid=kid_fit, share_beta=True, **kw)
         util.check_share(om, name, case, o, ge, kid_fit)
+    gk = golden(f'kp_{name}')
+    if 'sharewarm.a.trans' in gk:  # share_beta + warm start: the ridge reference is dropped (pt/lstsq.py:45-47)
+        _, tv, kw = util.warm_inputs(g, 'a')
+        o = H.fit_warm(md, kind, tv, share_beta=True, **kw)
+        util.check_share(om, name, 'a', o, gk, False, prefix='sharewarm')
 
 
 @pytest.mark.parametrize('name', ['smpl', 'smplx'])

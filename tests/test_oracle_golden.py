@@ -234,3 +234,26 @@ def test_scale_goldens(name, model_root, golden):
         if case in ('a', 'b'):  # the target really is a 1.1x body
             want = 1 / 1.1 if case == 'a' else 1.1
             assert np.abs(o['scale_corr'] - want).max() < 0.02
+
+
+@pytest.mark.parametrize('name', ['smpl', 'smplx'])
+def test_known_pose_option_goldens(name, model_root, golden):
+    """fit_with_known_pose with share_beta / scale_target / scale_fit / ridge references against the
+    reference's fixture (tests/golden/make_golden_knownpose.py)."""
+    g, gk = golden(name), golden(f'kp_{name}')
+    kind, md = util.load_md(model_root, name, g)
+    om, of = util.make_oracle(md, kind, np.float64)
+    fitters = {False: of, True: O.OracleFitter(om, enable_kid=True)}
+    n = 0
+    for case in util.KNOWN_POSE_CASES:
+        if f'knownpose.{case}.trans' not in gk:
+            continue
+        kid_fit, pose, tv, kw = util.known_pose_inputs(g, case)
+        o = fitters[kid_fit].fit_with_known_pose(pose, tv, **kw)
+        util.check_known_pose(name, case, o, gk, kid_fit)
+        n += 1
+    assert n >= 3
+    if 'sharewarm.a.trans' in gk:  # share_beta + warm start: the ridge reference is dropped (pt/lstsq.py:45-47)
+        _, tv, kw = util.warm_inputs(g, 'a')
+        o = util.make_oracle(md, kind)[1].fit(tv, share_beta=True, **kw)
+        util.check_share(om, name, 'a', o, gk, False, prefix='sharewarm')

@@ -171,12 +171,12 @@ def share_inputs(g, om, case):
     return kid_fit, tv, kw
 
 
-def check_share(om, name, case, o, ge, kid_fit):
+def check_share(om, name, case, o, ge, kid_fit, prefix='share'):
     """share_beta fit against the reference's fixture.  The shared-shape pipeline amplifies fp32
     reduction noise (the reference documents ~2e-3 in pose_rotvecs at the ankles, pt/bodyfitter.py
     :250-255), so the mesh gate is 5e-4 m here and the shared shape itself is pinned tightly."""
     keys = ('pose_rotvecs', 'shape_betas', 'trans') + (('kid_factor',) if kid_fit else ())
-    ref = {k: ge[f'share.{case}.{k}'] for k in keys}
+    ref = {k: ge[f'{prefix}.{case}.{k}'] for k in keys}
     assert np.abs(o['shape_betas'] - o['shape_betas'][:1]).max() == 0, case  # one shape for the batch
     assert np.abs(o['shape_betas'] - ref['shape_betas']).max() < (1e-3 if name == 'smpl' else 3e-3), case
     assert np.abs(o['trans'] - ref['trans']).max() < 1e-4, case
@@ -221,3 +221,54 @@ def check_scale(om, name, case, o, ge, kid_fit):
     va = om.forward(o['pose_rotvecs'], o['shape_betas'], o['trans'], **kw_o)['vertices']
     vb = om.forward(ref['pose_rotvecs'], ref['shape_betas'], ref['trans'], **kw_r)['vertices']
     assert np.linalg.norm(va - vb, axis=-1).max() < 1e-4, case
+
+
+# fit_with_known_pose with the options of the general shape solve (reference pt/bodyfitter.py:552-653 ->
+# _fit_shape_general :1104-1319): share_beta, scale_target / scale_fit, ridge references.
+# case -> (enable_kid, joints, weights, options)
+KNOWN_POSE_CASES = {
+    'a': (False, True, False, dict(share_beta=True, beta_regularizer=1.0)),
+    'b': (False, True, False, dict(scale_target=True, beta_regularizer=0.0)),
+    'c': (False, False, True, dict(scale_fit=True, beta_regularizer=1.0, scale_regularizer=0.5)),
+    'd': (True, True, True, dict(beta_regularizer=1.0, kid_regularizer=2.0, refs='bk')),
+    'e': (True, True, False, dict(share_beta=True, beta_regularizer=0.5, refs='bk')),
+    'f': (True, False, False, dict(scale_target=True, beta_regularizer=1.0, scale_regularizer=0.1, refs='b')),
+    'g': (False, True, False, dict(beta_regularizer=2.0, beta_regularizer2=0.5, refs='b4')),
+}
+
+
+def known_pose_inputs(g, case):
+    """pose = the fixture's true pose; targets = the fixture's noisy targets (scaled by 1.1 for the scale
+    options); ridge references = seeded offsets of the true betas ('b4': only 4 columns given)."""
+    kid_fit, joints, weights, kw = KNOWN_POSE_CASES[case]
+    kw = dict(kw)
+    refs = kw.pop('refs', '')
+    f = np.float32(1.1 if (kw.get('scale_target') or kw.get('scale_fit')) else 1.0)
+    rs = np.random.RandomState(123)
+    B = g['pose'].shape[0]
+    if 'b' in refs:
+        br = (g['betas'] + rs.randn(*g['betas'].shape) * 0.2).astype(np.float32)
+        kw['beta_regularizer_reference'] = br[:, :4].copy() if '4' in refs else br
+    if 'k' in refs:
+        kw['kid_regularizer_reference'] = (rs.rand(B) * 0.3).astype(np.float32)
+    kw['target_joints'] = g['target_joints'] * f if joints else None
+    kw['vertex_weights'] = g['vertex_weights'] if weights else None
+    kw['joint_weights'] = g['joint_weights'] if (weights and joints) else None
+    return kid_fit, g['pose'], g['target_vertices'] * f, kw
+
+
+def check_known_pose(name, case, o, gk, kid_fit, tol_scale=1.0):
+    """Shape / translation / scale of one solve against the reference's fixture.  The reference solves
+    these systems in fp32 (lstsq of the general path), so the gates are 1e-3-class on shape_betas."""
+    share = KNOWN_POSE_CASES[case][3].get('share_beta', False)
+    if share:
+        assert np.abs(o['shape_betas'] - o['shape_betas'][:1]).max() == 0, case
+    tb = (1e-3 if name == 'smpl' else 3e-3) * tol_scale
+    assert np.abs(o['shape_betas'] - gk[f'knownpose.{case}.shape_betas']).max() < tb, case
+    assert np.abs(o['trans'] - gk[f'knownpose.{case}.trans']).max() < 1e-4 * tol_scale, case
+    if kid_fit:
+        assert np.abs(o['kid_factor'] - gk[f'knownpose.{case}.kid_factor']).max() < 2e-3 * tol_scale, case
+    if f'knownpose.{case}.scale_corr' in gk:
+        assert np.abs(o['scale_corr'] - gk[f'knownpose.{case}.scale_corr']).max() < 1e-4 * tol_scale, case
+    else:
+        assert 'scale_corr' not in o or o['scale_corr'] is None
