@@ -164,6 +164,9 @@ int smplfit_fit_warm_f32(const smplfit_handle* h, const float* target_vertices,
  *   scale_mode -- BodyFitter.fit(scale_target=True) / (scale_fit=True): the LAST shape solve gets one more
  *   unknown, the refinement sees scaled targets resp. a scaled reference, the mean is added back scaled.
  *   shape_betas / kid_factor are returned as the reference returns them (undivided by the scale).
+ *   share_beta together with scale_mode: the scaled solve shares the shape and keeps one scale per
+ *   instance (lstsq_partial_share with n_shared = S, pt/lstsq.py:50-90): every instance contributes the
+ *   Schur complement of its scale entry, the S x S sums are solved once, the scales follow.
  * Zero-initialise the struct; fields left 0 / NULL mean "not given". */
 typedef int (*smplfit_share_allreduce_fn)(void* user, double* sums, int32_t count, void* hip_stream);
 

@@ -392,11 +392,28 @@ class OracleFitter:
             lam = np.concatenate([lam, [float(scale_reg)]])
             if reg_ref is not None:
                 reg_ref = np.concatenate([np.asarray(reg_ref, np.float64), np.zeros((B, 1))], 1)
-        if reg_ref is not None and not share_beta:
+        if reg_ref is not None and not share_beta:  # (share_beta with a scale unknown: below)
             # the all-shared branch of lstsq_partial_share calls lstsq WITHOUT l2_regularizer_rhs
             # (pt/lstsq.py:45-47): with share_beta the ridge pulls towards zero whatever the reference
             rhs_c = rhs_c + (lam[None] * np.asarray(reg_ref, np.float64))[..., None]
-        if share_beta:
+        if share_beta and scale_mode:
+            # shared shape, one scale per instance: lstsq_partial_share with n_shared = S (pt/lstsq.py
+            # :50-90).  Regressing the shared columns and the right-hand side on the independent column
+            # and solving the shared part on the residuals is the Schur complement of the scale entry.
+            # The ridge rows are appended to the design matrix with weight lambda and right-hand side
+            # lambda * reference (:52-61), so the reference enters the normal equations with lambda^2
+            # (the plain solve adds lambda * reference, :20-21) -- restated as the reference computes it.
+            if reg_ref is not None:
+                rhs_c = rhs_c + (lam[None] ** 2 * np.asarray(reg_ref, np.float64))[..., None]
+            Mfull = gram_c + np.diag(lam)[None]
+            n = S - 1
+            Mss, mv, c = Mfull[:, :n, :n], Mfull[:, :n, n:], Mfull[:, n:, n:]
+            rs, rho = rhs_c[:, :n], rhs_c[:, n:]
+            Msum = (Mss - mv @ np.swapaxes(mv, 1, 2) / c).sum(0)
+            xs = np.linalg.solve(Msum, (rs - mv * rho / c).sum(0))
+            sig = (rho - np.swapaxes(mv, 1, 2) @ xs[None]) / c
+            x = np.concatenate([np.broadcast_to(xs[None], rs.shape), sig], 1)
+        elif share_beta:
             # one shape for the whole batch: the regularised normal equations of all instances are summed
             # before the solve (pt/lstsq.py:24-26 via lstsq_partial_share :47-49; every instance keeps
             # its own centring, hence its own translation)

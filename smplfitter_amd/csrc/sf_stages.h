@@ -435,6 +435,14 @@ SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const doubl
 // scratch: doubles [NE+1 | (S+1)^2 | S+1 | S | 8] then floats.  Outputs: beta_out (S, UNDIVIDED — what the
 // reference returns and hands to the refinement, :1277-1283), beta_eval (S, divided by the scale for
 // scale_fit: the shape the mesh is evaluated at, :1289-1293), trans, scale, joints, jb.
+// share_beta with a scale unknown (lstsq_partial_share with n_shared = S, pt/lstsq.py:50-90: the shape
+// is shared by the batch, every instance keeps its scale): regressing out the independent column is
+// the Schur complement of the scale entry.  share 1 writes this instance's reduced S x S system
+// M_ss - m m^T / c and right-hand side r_s - m rho / c to cen[S*S + S] (layout of stage S) for the sum
+// over the batch; share 2 solves the summed system read from cen and recovers this instance's
+// sigma = (rho - m . x_s) / c.  In this branch the reference appends the ridge as ROWS of the design
+// matrix with weight lambda and right-hand side lambda * reference (:52-61), so reg_ref enters with
+// lambda^2 — restated as the reference computes it.
 // ---------------------------------------------------------------------------------------------
 SF_HD int scaled_solve_scratch_floats(int S) {
   return 2 * (ne_size(S) + 1 + (S + 1) * (S + 1) + (S + 1) + S + 8) + ((S + 8) / 4 * 4);
@@ -446,7 +454,8 @@ SF_HD void scaled_solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, cons
                               const float* mb, const float* tj, const float* jw, bool joint_block,
                               int mode, float beta_reg, float beta_reg2, float kid_reg, float scale_reg,
                               const float* reg_ref, float* beta_out, float* beta_eval, float* trans_out,
-                              float* scale_out, float* rjoints_out, float* jb_out) {
+                              float* scale_out, float* rjoints_out, float* jb_out, int share = 0,
+                              double* cen = nullptr) {
   const int J = tb.J, S = tb.S, S1 = S + 1, N = S + 1;
   const int NG = ne_ng(S), NE = ne_size(S);
   double* sum = reinterpret_cast<double*>(scratch);  // NE+1
@@ -521,34 +530,58 @@ SF_HD void scaled_solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, cons
     double r;
     if (i < S) {
       r = sum[NG + i] - (SA[i] * Sb[0] + SA[S + i] * Sb[1] + SA[2 * S + i] * Sb[2]) / W;
-      if (reg_ref) r += lam(i) * (double)reg_ref[i];
+      if (reg_ref) r += (share ? lam(i) * lam(i) : lam(i)) * (double)reg_ref[i];
     } else {
       r = q - (Sc[0] * Sb[0] + Sc[1] * Sb[1] + Sc[2] * Sb[2]) / W;
     }
     x[i] = r;
   }
   cx.sync();
-  for (int k = 0; k < N; ++k) {  // Cholesky, column by column
+  if (share == 1) {  // Schur complement of the scale entry: row S of M is (m, c), x[S] is rho
+    const double c = M[S * N + S], rho = x[S];
+    SF_FOR(k, S * S) {
+      const int i = k / S, j = k % S;
+      cen[k] = j <= i ? M[i * N + j] - M[S * N + i] * M[S * N + j] / c : 0.0;
+    }
+    SF_FOR(i, S) cen[S * S + i] = x[i] - M[S * N + i] * rho / c;
+    return;
+  }
+  int n = N;  // size of the system solved here
+  if (share == 2) {  // the summed reduced system; row S of M and x[S] stay this instance's own
+    SF_FOR(k, S * S) {
+      const int i = k / S, j = k % S;
+      if (j <= i) M[i * N + j] = cen[k];
+    }
+    SF_FOR(i, S) x[i] = cen[S * S + i];
+    n = S;
+    cx.sync();
+  }
+  for (int k = 0; k < n; ++k) {  // Cholesky, column by column
     if (cx.lane == 0) M[k * N + k] = sqrt(M[k * N + k]);
     cx.sync();
-    SF_FOR(i, N) if (i > k) M[i * N + k] /= M[k * N + k];
+    SF_FOR(i, n) if (i > k) M[i * N + k] /= M[k * N + k];
     cx.sync();
-    SF_FOR(idx, N * N) {
-      const int i = idx / N, j = idx % N;
+    SF_FOR(idx, n * n) {
+      const int i = idx / n, j = idx % n;
       if (j > k && i >= j) M[i * N + j] -= M[i * N + k] * M[j * N + k];
     }
     cx.sync();
   }
   if (cx.lane == 0) {
-    for (int i = 0; i < N; ++i) {
+    for (int i = 0; i < n; ++i) {
       double v = x[i];
       for (int k = 0; k < i; ++k) v -= M[i * N + k] * x[k];
       x[i] = v / M[i * N + i];
     }
-    for (int i = N - 1; i >= 0; --i) {
+    for (int i = n - 1; i >= 0; --i) {
       double v = x[i];
-      for (int k = i + 1; k < N; ++k) v -= M[k * N + i] * x[k];
+      for (int k = i + 1; k < n; ++k) v -= M[k * N + i] * x[k];
       x[i] = v / M[i * N + i];
+    }
+    if (share == 2) {  // this instance's scale from the shared shape
+      double v = x[S];
+      for (int j = 0; j < S; ++j) v -= M[S * N + j] * x[j];
+      x[S] = v / M[S * N + S];
     }
   }
   cx.sync();

@@ -427,8 +427,18 @@ int enqueue_solve(const DevModel& d, const Workspace& ws, int B, const FitOption
     sa.pair_form = pair_in;
     sa.use_ref = use_ref;
     sa.beta_reg = o.beta_reg; sa.beta_reg2 = o.beta_reg2; sa.kid_reg = o.kid_reg; sa.scale_reg = o.scale_reg;
-    hipLaunchKernelGGL(k_shape_solve_scaled, dim3(B), dim3(64),
-                       (size_t)sf::scaled_solve_scratch_floats(d.S) * 4, st, d, ws, sa);
+    const size_t lds = (size_t)sf::scaled_solve_scratch_floats(d.S) * 4;
+    if (o.share_beta) {  // shared shape, own scale: reduced systems, their sum, solve (pt/lstsq.py:50-90)
+      const int NC = d.S * d.S + d.S;
+      sa.share = 1;
+      sa.B = B;
+      hipLaunchKernelGGL(k_shape_solve_scaled, dim3(B), dim3(64), lds, st, d, ws, sa);
+      hipLaunchKernelGGL(k_share_reduce, dim3(1), dim3(512), 0, st, ws, B, NC);
+      if (o.share_allreduce && o.share_allreduce(o.share_user, ws.cen + (size_t)B * NC, NC, (void*)st) != 0)
+        return fail(SMPLFIT_ERR_HIP, "the share_allreduce callback failed");
+      sa.share = 2;
+    }
+    hipLaunchKernelGGL(k_shape_solve_scaled, dim3(B), dim3(64), lds, st, d, ws, sa);
   } else if (o.share_beta) {  // assemble per instance, sum over the batch, solve the sum + own translation
     const int NC = d.S * d.S + d.S;
     hipLaunchKernelGGL(k_shape_solve, dim3(B), dim3(64), solve_lds(d), st, d, ws, o.beta_reg,
@@ -990,10 +1000,6 @@ int smplfit_fit_ex_f32(const smplfit_handle* h, const smplfit_fit_args* args) {
     return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_ex_f32: scale_mode must be 0, 1 (scale_target) or 2 (scale_fit)");
   if (args->scale_mode && !args->scale_corr)
     return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_ex_f32: a scale option needs the scale_corr output");
-  if (args->scale_mode && o.share_beta)
-    return fail(SMPLFIT_ERR_UNSUPPORTED,
-                "smplfit_fit_ex_f32: share_beta together with a scale unknown (partially shared solve, "
-                "pt/lstsq.py:32-90) is not implemented");
   if (args->share_allreduce && !o.share_beta)
     return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_ex_f32: share_allreduce without share_beta");
   o.share_allreduce = args->share_allreduce;
@@ -1158,10 +1164,6 @@ int smplfit_shape_solve_ex_f32(const smplfit_handle* h, const smplfit_shape_solv
     return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_shape_solve_ex_f32: scale_mode must be 0, 1 (scale_target) or 2 (scale_fit)");
   if (args->scale_mode && !args->scale_corr)
     return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_shape_solve_ex_f32: a scale option needs the scale_corr output");
-  if (args->scale_mode && args->share_beta)
-    return fail(SMPLFIT_ERR_UNSUPPORTED,
-                "smplfit_shape_solve_ex_f32: share_beta together with a scale unknown (partially shared "
-                "solve, pt/lstsq.py:32-90) is not implemented");
   if (args->scale_mode && (args->vertices_out || args->joints_out))
     return fail(SMPLFIT_ERR_UNSUPPORTED, "smplfit_shape_solve_ex_f32: no mesh outputs with a scale unknown");
   if (args->share_allreduce && !args->share_beta)

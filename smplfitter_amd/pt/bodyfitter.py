@@ -96,9 +96,6 @@ class BodyFitter(nn.Module):
             requested_keys = ['pose_rotvecs']
         if scale_target and scale_fit:  # same check, same message as pt/bodyfitter.py:858-859
             raise ValueError('Only one of estim_scale_target and estim_scale_fit can be True')
-        if share_beta and (scale_target or scale_fit):
-            raise NotImplementedError('share_beta together with a scale unknown (partially shared solve, '
-                                      'pt/lstsq.py:32-90) is not implemented')
         scale_mode = 1 if scale_target else 2 if scale_fit else 0
         if share_beta_group is not None:
             if not share_beta:
@@ -236,9 +233,6 @@ class BodyFitter(nn.Module):
         (pt/lstsq.py:45-47).  ``share_beta_group``: as in :meth:`fit`."""
         if scale_target and scale_fit:  # same check, same message as pt/bodyfitter.py:858-859
             raise ValueError('Only one of estim_scale_target and estim_scale_fit can be True')
-        if share_beta and (scale_target or scale_fit):
-            raise NotImplementedError('share_beta together with a scale unknown (partially shared solve, '
-                                      'pt/lstsq.py:32-90) is not implemented')
         if share_beta_group is not None and not share_beta:
             raise ValueError('share_beta_group needs share_beta=True')
         if kid_regularizer_reference is not None and not self.enable_kid:

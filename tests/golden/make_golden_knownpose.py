@@ -3,7 +3,8 @@ scale_target / scale_fit, ridge references; reference pt/bodyfitter.py:552-653 -
 by running the REFERENCE itself in the build container on the inputs of ``golden_<kind>.npz``.
 
 Stored: ``knownpose.<case>.{shape_betas,trans[,kid_factor][,scale_corr]}`` for ``util.KNOWN_POSE_CASES``,
-and ``sharewarm.a.*``: ``fit(share_beta=True)`` on the warm-start inputs of ``util.WARM_CASES['a']`` (the
+``sharescale.<case>.*`` for ``fit(share_beta=True, scale_target / scale_fit=True)`` (``util.SHARE_SCALE_CASES``:
+all-shared solves, then the partially shared last solve, pt/lstsq.py:50-90) and ``sharewarm.a.*``: ``fit(share_beta=True)`` on the warm-start inputs of ``util.WARM_CASES['a']`` (the
 all-shared solve of the reference ignores the ridge reference the warm start hands it, pt/lstsq.py:45-47).
 
 Usage:  python tests/golden/make_golden_knownpose.py
@@ -24,7 +25,8 @@ import smplfitter.pt as ref  # noqa: E402
 from smplfitter_amd import synth  # noqa: E402
 
 sys.path.insert(0, osp.join(HERE, '..'))
-from util import KNOWN_POSE_CASES, known_pose_inputs, warm_inputs  # noqa: E402
+from util import (KNOWN_POSE_CASES, SHARE_SCALE_CASES, known_pose_inputs, load_md, make_oracle,  # noqa: E402
+                  share_scale_inputs, warm_inputs)
 
 
 def main():
@@ -38,7 +40,7 @@ def main():
         out = {}
         with torch.no_grad():
             for case in KNOWN_POSE_CASES:
-                if kind != 'smpl' and case not in ('a', 'b', 'd'):
+                if kind != 'smpl' and case not in ('a', 'b', 'd', 'h'):
                     continue
                 kid_fit, pose, tv, kw = known_pose_inputs(g, case)
                 kwt = {k: (T(v) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
@@ -46,6 +48,18 @@ def main():
                 for k in ('shape_betas', 'trans', 'kid_factor', 'scale_corr'):
                     if r.get(k) is not None:
                         out[f'knownpose.{case}.{k}'] = r[k].numpy()
+            # share_beta with a scale unknown; targets from the repo's numpy forward (pinned by golden_<kind>.npz)
+            om_, _ = make_oracle(load_md(root, kind, g)[1], kind)
+            for case in SHARE_SCALE_CASES:
+                if kind != 'smpl' and case != 'a':
+                    continue
+                kid_fit, tv, kw = share_scale_inputs(g, om_, case)
+                kwt = {k: (T(v) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+                r = fitters[kid_fit].fit(T(tv), share_beta=True,
+                                         requested_keys=['pose_rotvecs', 'shape_betas', 'trans'], **kwt)
+                for k in ('pose_rotvecs', 'shape_betas', 'trans', 'kid_factor', 'scale_corr'):
+                    if r.get(k) is not None:
+                        out[f'sharescale.{case}.{k}'] = r[k].numpy()
             if kind == 'smpl':
                 _, tv, kw = warm_inputs(g, 'a')
                 kwt = {k: (T(v) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}

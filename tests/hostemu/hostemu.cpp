@@ -227,6 +227,19 @@ struct Emu {
   bool share_beta = false;  // one shape for the batch: assemble, sum in instance order, solve the sum
   smplfit_share_allreduce_fn share_allreduce = nullptr;  // as smplfit_fit_args.share_allreduce, host memory
   void* share_user = nullptr;
+  // row B of cen = sum of rows 0..B-1 in the order of k_share_reduce, then the sum over the ranks
+  void share_sum(double* cen, int NC) {
+    for (int e = 0; e < NC; ++e) {
+      double a[4] = {0, 0, 0, 0};
+      int b = 0;
+      for (; b + 3 < B; b += 4)
+        for (int q = 0; q < 4; ++q) a[q] += cen[(size_t)(b + q) * NC + e];
+      for (; b < B; ++b) a[0] += cen[(size_t)b * NC + e];
+      cen[(size_t)B * NC + e] = (a[0] + a[1]) + (a[2] + a[3]);
+    }
+    if (share_allreduce) share_allreduce(share_user, cen + (size_t)B * NC, NC, nullptr);
+  }
+
   void k4(float reg, float reg2, float kid_reg) {
     const int J = t.J, NE1 = sf::ne_size(S) + 1, NC = S * S + S;
     HostCtx cx;
@@ -245,15 +258,7 @@ struct Emu {
       return;
     }
     for (int b = 0; b < B; ++b) stage(b, 1, cen.data() + (size_t)b * NC);
-    for (int e = 0; e < NC; ++e) {  // the summation order of k_share_reduce
-      double a[4] = {0, 0, 0, 0};
-      int b = 0;
-      for (; b + 3 < B; b += 4)
-        for (int q = 0; q < 4; ++q) a[q] += cen[(size_t)(b + q) * NC + e];
-      for (; b < B; ++b) a[0] += cen[(size_t)b * NC + e];
-      cen[(size_t)B * NC + e] = (a[0] + a[1]) + (a[2] + a[3]);
-    }
-    if (share_allreduce) share_allreduce(share_user, cen.data() + (size_t)B * NC, NC, nullptr);
+    share_sum(cen.data(), NC);
     for (int b = 0; b < B; ++b) stage(b, 2, cen.data() + (size_t)B * NC);
   }
 
@@ -370,6 +375,7 @@ int fit_impl(const sf::HostTables& t, const float* tv, const float* tj, const fl
       std::vector<float> scratch(sf::scaled_solve_scratch_floats(S) + 8);
       float* sb = scratch.data();
       while ((uintptr_t)sb & 15) ++sb;
+      std::vector<float> vextra((size_t)B * 32, 0.f);
       for (int b = 0; b < B; ++b) {
         std::vector<double> dacc(NX, 0.0);
         for (int i0 = 0; i0 < t.V; i0 += 64) {  // per-lane fp32 partials as on the GPU, then summed
@@ -384,17 +390,27 @@ int fit_impl(const sf::HostTables& t, const float* tv, const float* tj, const fl
             for (int k = 0; k < NX; ++k) dacc[k] += (double)acc[k];
           }
         }
-        float vextra[32];
-        for (int k = 0; k < NX; ++k) vextra[k] = (float)dacc[k];
+        for (int k = 0; k < NX; ++k) vextra[(size_t)b * 32 + k] = (float)dacc[k];
+      }
+      auto stage = [&](int b, int share, double* cen) {
         sf::scaled_solve_stage(cx0, e.jt, sb, e.gramv.data() + (size_t)b * NE1, e.gramj.data() + (size_t)b * NE1,
-                               vextra, e.pext.data() + (size_t)b * t.J * 3 * (S + 1), e.jd_b(b),
-                               e.use_pair_gram ? e.mbj.data() + (size_t)b * t.J * 3 : nullptr,
+                               vextra.data() + (size_t)b * 32, e.pext.data() + (size_t)b * t.J * 3 * (S + 1),
+                               e.jd_b(b), e.use_pair_gram ? e.mbj.data() + (size_t)b * t.J * 3 : nullptr,
                                joints ? e.tjc.data() + (size_t)b * t.J * 3 : nullptr,
                                eff_j ? jw + (size_t)b * t.J : nullptr, joints, w.scale_mode, reg, reg2, kid_reg,
                                w.scale_reg, e.regref.empty() ? nullptr : e.regref.data() + (size_t)b * S,
                                beta_und.data() + (size_t)b * S, e.beta.data() + (size_t)b * S,
                                e.trans.data() + (size_t)b * 3, scale.data() + b,
-                               e.rjoints.data() + (size_t)b * t.J * 3, e.jb.data() + (size_t)b * t.J * 4);
+                               e.rjoints.data() + (size_t)b * t.J * 3, e.jb.data() + (size_t)b * t.J * 4, share, cen);
+      };
+      if (!e.share_beta) {
+        for (int b = 0; b < B; ++b) stage(b, 0, nullptr);
+      } else {  // shared shape, own scale: mirrors the three launches of enqueue_solve
+        const int NC = S * S + S;
+        std::vector<double> cen((size_t)(B + 1) * NC, 0.0);
+        for (int b = 0; b < B; ++b) stage(b, 1, cen.data() + (size_t)b * NC);
+        e.share_sum(cen.data(), NC);
+        for (int b = 0; b < B; ++b) stage(b, 2, cen.data() + (size_t)B * NC);
       }
     } else {
       e.k4(reg, reg2, kid_reg);

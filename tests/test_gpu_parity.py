@@ -165,10 +165,6 @@ def test_edge_batches(model_root, golden, dev):
     assert e['vertices'].shape == (0, 6890, 3)
     with pytest.raises(ValueError):
         f.fit(tv, tj, scale_target=True, scale_fit=True)
-    with pytest.raises(NotImplementedError):
-        f.fit(tv, tj, scale_fit=True, share_beta=True)
-    with pytest.raises(NotImplementedError):
-        f.fit_with_known_pose(torch.zeros(37, 72, device=dev), tv, tj, share_beta=True, scale_target=True)
     with pytest.raises(ValueError):
         f.fit_with_known_pose(torch.zeros(37, 72, device=dev), tv, tj, scale_target=True, scale_fit=True)
     with pytest.raises(ValueError):
@@ -532,6 +528,30 @@ def test_known_pose_option_goldens(name, model_root, golden, dev):
     assert np.abs(o['trans'] - ref['trans']).max() < 2e-5
 
 
+@pytest.mark.parametrize('name', ['smpl', 'smplx'])
+def test_share_scale_goldens(name, model_root, golden, dev):
+    """share_beta with a scale unknown: all-shared solves, then the partially shared last solve
+    (pt/lstsq.py:50-90) in fit, and the same solve in fit_with_known_pose (cases h, i of
+    test_known_pose_option_goldens)."""
+    from smplfitter_amd.pt import BodyFitter
+
+    g, gk = golden(name), golden(f'kp_{name}')
+    kind, md = util.load_md(model_root, name, g)
+    om, _ = util.make_oracle(md, kind)
+    m, f = get_model(model_root, name, g, dev)
+    fitters = {False: f, True: BodyFitter(m, enable_kid=True)}
+    n = 0
+    for case in util.SHARE_SCALE_CASES:
+        if f'sharescale.{case}.trans' not in gk:
+            continue
+        kid_fit, tv, kw = util.share_scale_inputs(g, om, case)
+        kwt = {k: (t(v, dev) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+        o = to_np(fitters[kid_fit].fit(t(tv, dev), share_beta=True, requested_keys=['pose_rotvecs'], **kwt))
+        util.check_share_scale(om, name, case, o, gk, kid_fit)
+        n += 1
+    assert n >= 1
+
+
 def _share_rank(rank, world, backend, port, root, tmp):
     """One rank of a sharded share_beta fit; every rank drives cuda:0 (the box has one GPU)."""
     import torch.distributed as dist
@@ -720,7 +740,7 @@ def test_cabi_error_paths(model_root, golden, dev):
     for over, exc, text in (
         (dict(scale_mode=3, scale_corr=out['s'].data_ptr()), ValueError, 'scale_mode'),
         (dict(scale_mode=1), ValueError, 'scale_corr'),
-        (dict(scale_mode=1, scale_corr=out['s'].data_ptr(), share_beta=1), NotImplementedError, 'share_beta'),
+        (dict(share_allreduce=_lib.ShareAllreduceFn(lambda *a: 0)), ValueError, 'share_allreduce'),
         (dict(num_iter=0), ValueError, 'num_iter'),
         (dict(target_vertices=None), ValueError, 'null'),
         (dict(initial_kid_factor=out['s'].data_ptr()), ValueError, 'kid'),

@@ -167,3 +167,21 @@ def test_scale_goldens(name, model_root, golden):
         kid_fit, tv, kw = util.scale_inputs(g, case)
         o = H.fit_warm(md, kind, tv, enable_kid=kid_fit, **kw)
         util.check_scale(om, name, case, o, ge, kid_fit)
+
+
+@pytest.mark.parametrize('name', ['smpl', 'smplx'])
+def test_share_scale_goldens(name, model_root, golden):
+    """share_beta with a scale unknown through the shared stage code: the Schur-reduced systems of the
+    scaled solve stage, their sum, the shared solve with every instance's own scale."""
+    g, gk = golden(name), golden(f'kp_{name}')
+    kind, md = util.load_md(model_root, name, g)
+    om, _ = util.make_oracle(md, kind)
+    n = 0
+    for case in util.SHARE_SCALE_CASES:
+        if f'sharescale.{case}.trans' not in gk:
+            continue
+        kid_fit, tv, kw = util.share_scale_inputs(g, om, case)
+        o = H.fit_warm(md, kind, tv, enable_kid=kid_fit, share_beta=True, **kw)
+        util.check_share_scale(om, name, case, o, gk, kid_fit)
+        n += 1
+    assert n >= 1

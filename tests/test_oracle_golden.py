@@ -257,3 +257,21 @@ def test_known_pose_option_goldens(name, model_root, golden):
         _, tv, kw = util.warm_inputs(g, 'a')
         o = util.make_oracle(md, kind)[1].fit(tv, share_beta=True, **kw)
         util.check_share(om, name, 'a', o, gk, False, prefix='sharewarm')
+
+
+@pytest.mark.parametrize('name', ['smpl', 'smplx'])
+def test_share_scale_goldens(name, model_root, golden):
+    """fit(share_beta=True) with a scale unknown: the partially shared last solve (pt/lstsq.py:50-90)."""
+    g, gk = golden(name), golden(f'kp_{name}')
+    kind, md = util.load_md(model_root, name, g)
+    om, of = util.make_oracle(md, kind)
+    fitters = {False: of, True: O.OracleFitter(om, enable_kid=True)}
+    n = 0
+    for case in util.SHARE_SCALE_CASES:
+        if f'sharescale.{case}.trans' not in gk:
+            continue
+        kid_fit, tv, kw = util.share_scale_inputs(g, om, case)
+        o = fitters[kid_fit].fit(tv, share_beta=True, **kw)
+        util.check_share_scale(om, name, case, o, gk, kid_fit)
+        n += 1
+    assert n >= 1

@@ -234,6 +234,10 @@ KNOWN_POSE_CASES = {
     'e': (True, True, False, dict(share_beta=True, beta_regularizer=0.5, refs='bk')),
     'f': (True, False, False, dict(scale_target=True, beta_regularizer=1.0, scale_regularizer=0.1, refs='b')),
     'g': (False, True, False, dict(beta_regularizer=2.0, beta_regularizer2=0.5, refs='b4')),
+    # shared shape + one scale per instance: the partially shared solve (pt/lstsq.py:50-90)
+    'h': (False, True, False, dict(share_beta=True, scale_target=True, beta_regularizer=1.0)),
+    'i': (True, True, True, dict(share_beta=True, scale_fit=True, beta_regularizer=0.5, scale_regularizer=0.3,
+                                 refs='bk')),
 }
 
 
@@ -272,3 +276,47 @@ def check_known_pose(name, case, o, gk, kid_fit, tol_scale=1.0):
         assert np.abs(o['scale_corr'] - gk[f'knownpose.{case}.scale_corr']).max() < 1e-4 * tol_scale, case
     else:
         assert 'scale_corr' not in o or o['scale_corr'] is None
+
+
+# fit(share_beta=True) with a scale unknown: all-shared solves, then the partially shared LAST solve
+# (pt/lstsq.py:50-90).  case -> (enable_kid, scale option, weights, warm start, fit kwargs)
+SHARE_SCALE_CASES = {
+    'a': (False, 'scale_target', False, False, dict(num_iter=2, beta_regularizer=1.0)),
+    'b': (True, 'scale_fit', True, True, dict(num_iter=2, beta_regularizer=0.5, scale_regularizer=0.2,
+                                              kid_regularizer=2.0)),
+    'c': (False, 'scale_fit', False, False, dict(num_iter=1, beta_regularizer=0.0, final_adjust_rots=False)),
+}
+
+
+def share_scale_inputs(g, om, case):
+    """One body shape in the fixture's poses (+3 mm noise), scaled by 1.1; joints always given."""
+    kid_fit, opt, weights, warm, kw = SHARE_SCALE_CASES[case]
+    rs = np.random.RandomState(78)
+    B = g['pose'].shape[0]
+    betas = np.repeat(g['betas'][:1], B, 0)
+    fw = om.forward(g['pose'], betas, g['trans'])
+    f = np.float32(1.1)
+    tv = ((fw['vertices'] + rs.randn(*fw['vertices'].shape) * 0.003) * f).astype(np.float32)
+    kw = dict(kw)
+    kw[opt] = True
+    kw['target_joints'] = (fw['joints'] * f).astype(np.float32)
+    kw['vertex_weights'] = g['vertex_weights'] if weights else None
+    kw['joint_weights'] = g['joint_weights'] if weights else None
+    if warm:
+        kw['initial_pose_rotvecs'] = (g['pose'] + rs.randn(*g['pose'].shape) * 0.05).astype(np.float32)
+        kw['initial_shape_betas'] = (betas + rs.randn(*betas.shape) * 0.2).astype(np.float32)
+    return kid_fit, tv, kw
+
+
+def check_share_scale(om, name, case, o, gk, kid_fit):
+    keys = ('pose_rotvecs', 'shape_betas', 'trans', 'scale_corr') + (('kid_factor',) if kid_fit else ())
+    ref = {k: gk[f'sharescale.{case}.{k}'] for k in keys}
+    assert np.abs(o['shape_betas'] - o['shape_betas'][:1]).max() == 0, case  # one shape for the batch
+    assert np.abs(o['scale_corr'] - ref['scale_corr']).max() < 2e-4, case
+    assert np.abs(o['shape_betas'] - ref['shape_betas']).max() < (1e-3 if name == 'smpl' else 3e-3), case
+    assert np.abs(o['trans'] - ref['trans']).max() < 2e-4, case
+    kw_o = dict(kid_factor=o['kid_factor']) if kid_fit else {}
+    kw_r = dict(kid_factor=ref['kid_factor']) if kid_fit else {}
+    va = om.forward(o['pose_rotvecs'], o['shape_betas'], o['trans'], **kw_o)['vertices']
+    vb = om.forward(ref['pose_rotvecs'], ref['shape_betas'], ref['trans'], **kw_r)['vertices']
+    assert np.linalg.norm(va - vb, axis=-1).max() < 5e-4, case
