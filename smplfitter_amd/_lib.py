@@ -14,7 +14,8 @@ import os.path as osp
 import numpy as np
 
 _HERE = osp.dirname(osp.abspath(__file__))
-LIB_PATH = osp.join(_HERE, 'libsmplfit_hip.so')
+# SMPLFIT_LIB: another build of the same library (A/B measurements of kernel variants)
+LIB_PATH = os.getenv('SMPLFIT_LIB') or osp.join(_HERE, 'libsmplfit_hip.so')
 
 SMPLFIT_OK = 0
 SMPLFIT_ERR_BAD_ARG = -1

@@ -234,7 +234,8 @@ bool use_bm() {
 // Small vertex subsets stay on the wave-per-instance kernels: the pair-Gram and combine passes cost the
 // same per instance whatever V is (measured at V = 1024, B = 16384: 4.15 M fits/s batch-major vs 4.63 M).
 bool bm_applies(const DevModel& d) {
-  return use_bm() && d.KW == 4 && d.S == 10 && d.ngroups > 0 && d.V >= 2048;
+  // Vp > V: the batch-major loops run their out-of-range steps on the first padding slot
+  return use_bm() && d.KW == 4 && d.S == 10 && d.ngroups > 0 && d.V >= 2048 && d.Vp > d.V;
 }
 
 template <int S, int KW>
