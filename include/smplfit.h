@@ -95,6 +95,8 @@ enum smplfit_table_id {
   SMPLFIT_TAB_ADJ_FLAG = 5,        /* (J)  1 if refined by the final adjustment                 */
   SMPLFIT_TAB_USED_PART = 6,       /* (J)  1 if the part's vertices enter the part sums         */
   SMPLFIT_TAB_SEGMENTS = 7,        /* (nseg,3) start, count, part                               */
+  SMPLFIT_TAB_VERTEX_GROUPS = 8,   /* (ngroups,5) start, count, part, used, joints: the workgroup
+                                      units of the batch-major vertex kernels                    */
 };
 int smplfit_get_table(const smplfit_handle* h, int table_id, int32_t* dst, size_t cap, size_t* n);
 

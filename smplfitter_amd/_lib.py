@@ -26,7 +26,7 @@ SMPLFIT_CREATE_HOST_ONLY = 1
 
 TABLE_IDS = dict(
     part_assignment=0, sort_perm=1, part_type=2, fk_order=3, fk_level_start=4, adj_flag=5,
-    used_part=6, segments=7,
+    used_part=6, segments=7, vertex_groups=8,
 )
 
 # every symbol include/smplfit.h declares

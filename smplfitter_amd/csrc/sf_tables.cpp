@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -250,12 +251,14 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
     t.groups.clear();
     const int bs = t.brec_stride(), bw = t.brec_w(), bd = t.brec_d();
     t.brec.assign((size_t)Vp * bs, 0.f);
+    // A maximal run is then cut into equal pieces of at most `cap` vertices: the groups are the
+    // workgroup units of the batch-major kernels, and a few hundred-vertex groups per instance block
+    // (SMPL: 22 of 224..483) leave the chip with ~1.25 uneven rounds of workgroups (cap 256: residual
+    // pass 231 -> 209 us, LBS pass 158 -> 139 us at B = 4096; below ~128 the staging + combine cost wins).
+    int cap = 256;
+    if (const char* e = std::getenv("SMPLFIT_GROUP_CAP")) cap = std::max(16, std::atoi(e));
     for (int i = 0; i < V;) {
       const int p = t.slot_part[i];
-      VertexGroup g{};
-      g.start = i;
-      g.part = p;
-      g.used = t.used_part[p] ? 1 : 0;
       uint64_t set = 0;
       int e = i;
       while (e < V && t.slot_part[e] == p) {
@@ -265,34 +268,44 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
         ++e;
       }
       if (e == i) return "smplfit_create: a vertex has more skinning joints than a vertex group holds";
-      g.count = e - i;
-      int local[kMaxJoints];
-      for (int j = 0; j < J; ++j)
-        if ((set >> j) & 1) {
-          local[j] = g.nq;
-          g.joints[g.nq++] = j;
-        }
-      for (int q = g.nq; q < kGroupJoints; ++q) g.joints[q] = g.joints[0];
-      for (int s = i; s < e; ++s) {
-        float* rec = t.brec.data() + (size_t)s * bs;
-        for (int s2 = 0; s2 < S; ++s2) {
-          for (int c = 0; c < 3; ++c) rec[c * S + s2] = t.sd[(size_t)(c * S + s2) * Vp + s];
-        }
-        for (int k = 0; k < t.KW; ++k) rec[bw + k] = t.wval[(size_t)k * Vp + s];
-        for (int q = 0; q < t.KW / 4; ++q) {
-          uint32_t w = 0;
-          for (int k = 0; k < 4; ++k) {
-            const int pair = q * 4 + k;
-            const float wv = t.wval[(size_t)pair * Vp + s];
-            const int jj = (int)((t.widx[(size_t)q * Vp + s] >> (8 * k)) & 0xffu);
-            const int ls = wv != 0.f ? local[jj] : 0;  // zero-weight padding pairs point at slot 0
-            w |= (uint32_t)ls << (8 * k);
-            if (wv != 0.f) rec[bd + ls] += wv;
+      const int pieces = (e - i + cap - 1) / cap;
+      for (int pc = 0; pc < pieces; ++pc) {
+        const int a = i + (int)((int64_t)(e - i) * pc / pieces), b = i + (int)((int64_t)(e - i) * (pc + 1) / pieces);
+        VertexGroup g{};
+        g.start = a;
+        g.count = b - a;
+        g.part = p;
+        g.used = t.used_part[p] ? 1 : 0;
+        uint64_t pset = 0;
+        for (int s = a; s < b; ++s) pset |= jmask[t.perm[s]];
+        int local[kMaxJoints];
+        for (int j = 0; j < J; ++j)
+          if ((pset >> j) & 1) {
+            local[j] = g.nq;
+            g.joints[g.nq++] = j;
           }
-          std::memcpy(rec + bw + t.KW + q, &w, 4);
+        for (int q = g.nq; q < kGroupJoints; ++q) g.joints[q] = g.joints[0];
+        for (int s = a; s < b; ++s) {
+          float* rec = t.brec.data() + (size_t)s * bs;
+          for (int s2 = 0; s2 < S; ++s2) {
+            for (int c = 0; c < 3; ++c) rec[c * S + s2] = t.sd[(size_t)(c * S + s2) * Vp + s];
+          }
+          for (int k = 0; k < t.KW; ++k) rec[bw + k] = t.wval[(size_t)k * Vp + s];
+          for (int q = 0; q < t.KW / 4; ++q) {
+            uint32_t w = 0;
+            for (int k = 0; k < 4; ++k) {
+              const int pair = q * 4 + k;
+              const float wv = t.wval[(size_t)pair * Vp + s];
+              const int jj = (int)((t.widx[(size_t)q * Vp + s] >> (8 * k)) & 0xffu);
+              const int ls = wv != 0.f ? local[jj] : 0;  // zero-weight padding pairs point at slot 0
+              w |= (uint32_t)ls << (8 * k);
+              if (wv != 0.f) rec[bd + ls] += wv;
+            }
+            std::memcpy(rec + bw + t.KW + q, &w, 4);
+          }
         }
+        t.groups.push_back(g);
       }
-      t.groups.push_back(g);
       i = e;
     }
     t.cpackB.assign(t.segments.size() * 64 * cs, 0.f);

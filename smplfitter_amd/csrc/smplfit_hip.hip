@@ -920,6 +920,16 @@ int smplfit_get_table(const smplfit_handle* h, int table_id, int32_t* dst, size_
       }
       src = &tmp;
       break;
+    case SMPLFIT_TAB_VERTEX_GROUPS:
+      for (auto& g : t.groups) {
+        tmp.push_back(g.start);
+        tmp.push_back(g.count);
+        tmp.push_back(g.part);
+        tmp.push_back(g.used);
+        tmp.push_back(g.nq);
+      }
+      src = &tmp;
+      break;
     default: return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_get_table: unknown table id");
   }
   *n = src->size();
