@@ -21,7 +21,7 @@ torch.cuda.synchronize()
 lib = _lib.load()
 st = torch.cuda.current_stream(dev).cuda_stream
 out = {}
-for name, kid in (('gemm', 2), ('accum', 3), ('solve', 4), ('lbs', 5)):
+for name, kid in (('gemm', 2), ('accum', 3), ('solve', 4), ('lbs', 5), ('pair_gram', 6), ('transpose', 7)):
     ms = C.c_float()
     _lib.check(lib.smplfit_time_kernel_f32(h.ptr, kid, B, 10, C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(st), C.byref(ms)))
     out[name] = round(ms.value * 1e3, 1)
