@@ -703,7 +703,7 @@ int upload(smplfit_handle* h, const std::vector<T>& src, const T** dst) {
 int chunk_plan(int batch, int* sizes) {
   static const int want = [] {
     const char* e = getenv("SMPLFIT_CHUNKS");
-    int v = e ? atoi(e) : 3;  // measured at B = 4096 (batch-major kernels): 1 chunk 1.23 M fits/s, 2: 1.30 M, 3: 1.31 M, 4: 1.31 M
+    int v = e ? atoi(e) : 2;  // measured at B = 4096 (batch-major kernels, r01_h): 1 chunk 1.30 M fits/s, 2: 1.43 M, 3: 1.41 M, 4: 1.37 M
     return v < 1 ? 1 : (v > kMaxChunks ? kMaxChunks : v);
   }();
   int n = want;
