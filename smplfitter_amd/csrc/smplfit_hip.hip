@@ -237,7 +237,8 @@ bool use_bm() {
 // same per instance whatever V is (measured at V = 1024, B = 16384: 4.15 M fits/s batch-major vs 4.63 M).
 bool bm_applies(const DevModel& d) {
   // Vp > V: the batch-major loops run their out-of-range steps on the first padding slot
-  return use_bm() && d.KW == 4 && d.S == 10 && d.ngroups > 0 && d.V >= 2048 && d.Vp > d.V;
+  // (below ~1000 vertices the staging of a workgroup's joints outweighs its vertex work)
+  return use_bm() && d.KW == 4 && d.S == 10 && d.ngroups > 0 && d.V >= 1024 && d.Vp > d.V;
 }
 
 // joint rows of the current rotations, instance-innermost, for k_pair_gram_bm

@@ -36,6 +36,9 @@ def run(name, kind, B, subset=None, steps=10):
 run('C2 smpl', 'smpl', 4096)
 run('C3 smplx', 'smplx', 4096)
 run('C4 smpl-1024', 'smpl', 16384, subset=1024)
+if os.getenv('C4_SUBSET'):
+    n = int(os.environ['C4_SUBSET'])
+    run(f'C4x smpl-{n}', 'smpl', 16384, subset=n)
 run('plumbing smpl B=32', 'smpl', 32)
 
 
