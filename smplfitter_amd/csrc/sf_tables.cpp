@@ -257,10 +257,10 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
     const int bs = t.brec_stride(), bw = t.brec_w(), bd = t.brec_d();
     t.brec.assign((size_t)Vp * bs, 0.f);
     // A maximal run is then cut into equal pieces of at most `cap` vertices: the groups are the
-    // workgroup units of the batch-major kernels, and a few hundred-vertex groups per instance block
-    // (SMPL: 22 of 224..483) leave the chip with ~1.25 uneven rounds of workgroups (cap 256: residual
-    // pass 231 -> 209 us, LBS pass 158 -> 139 us at B = 4096; below ~128 the staging + combine cost wins).
-    int cap = 256;
+    // workgroup units of the batch-major kernels, and SMPL's 22 runs of 224..483 vertices leave the chip
+    // with uneven rounds of workgroups.  Measured at B = 4096 with two chunks (M fits/s): no cut 1.43,
+    // cap 448 / 384: 1.48, 256: 1.46, 192: 1.46; below ~128 the staging + combine cost wins.
+    int cap = 384;
     if (const char* e = std::getenv("SMPLFIT_GROUP_CAP")) cap = std::max(16, std::atoi(e));
     for (int i = 0; i < V;) {
       const int p = t.slot_part[i];
