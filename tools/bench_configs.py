@@ -72,3 +72,6 @@ def run_graphed(B=32, steps=200):
 
 run_graphed(32)
 run_graphed(256)
+if os.getenv('GRAPH_BIG'):
+    run_graphed(4096, steps=30)
+    run_graphed(1024, steps=50)
