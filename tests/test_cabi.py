@@ -79,6 +79,20 @@ def test_host_tables_match_reference_structure(lib, name, model_root, golden):
     for s, c, p in seg:  # every segment is one part, at most one wave wide
         assert 0 < c <= 64 and (of.part[perm[s:s + c]] == p).all()
     assert h.info.skin_width == 4 and h.info.padded_vertices % 128 == 0
+    # vertex groups (workgroup units of the batch-major kernels): a partition of the sorted slots into
+    # runs of one part, at most 384 vertices and 12 skinning joints each, used parts first; and at least
+    # one padding slot behind the vertices whenever those kernels can apply
+    grp = h.table('vertex_groups').reshape(-1, 5)
+    assert grp[0, 0] == 0 and (grp[1:, 0] == grp[:-1, 0] + grp[:-1, 1]).all()
+    assert grp[-1, 0] + grp[-1, 1] == V
+    assert (grp[:, 1] > 0).all() and (grp[:, 1] <= 384).all() and (grp[:, 4] >= 1).all() and (grp[:, 4] <= 12).all()
+    for s, c, p, u, nq in grp:
+        assert (of.part[perm[s:s + c]] == p).all() and u == int(p in of.used_parts)
+        joints = np.unique(np.nonzero(md.weights[perm[s:s + c]])[1])
+        assert len(joints) == nq
+    assert (np.diff(grp[:, 3]) <= 0).all()  # used groups first
+    if V >= 1024:
+        assert h.info.padded_vertices > V
     assert h.workspace_bytes(64) > 0
     h.close()
 
