@@ -6,8 +6,14 @@
 
 #if defined(__HIPCC__)
 #define SF_HD __host__ __device__ __forceinline__
+// partial unrolling of loops with run-time trip counts whose bodies are LDS / table reads: the reads of
+// several iterations are then issued together instead of one memory latency per iteration (the
+// accumulation order is unchanged)
+#define SF_UNROLL(n) _Pragma(SF_STR_(unroll n))
+#define SF_STR_(x) #x
 #else
 #define SF_HD inline
+#define SF_UNROLL(n)
 #endif
 
 // Scheduling fence for the device compiler: stops it from hoisting the LDS loads of later phases

@@ -253,6 +253,7 @@ SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
     if (vertex_sa_closed_form && e >= NG + S && e < NG + 4 * S) {
       // vertex-block SA with unit weights, sum_v Jac_v[c][i] = sum_j (G_j CS_j)[c][i] + cw_j T'_j[c][i]
       const int c = (e - NG - S) / S, i = (e - NG - S) % S;
+      SF_UNROLL(4)
       for (int j = 0; j < J; ++j) {
         const float* Gj = sh.G + j * 9 + c * 3;
         const float* cs = tb.cs_joint + j * 3 * S + i;
@@ -268,18 +269,21 @@ SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
           ++i;
         }
         const int jj = i + r;
+        SF_UNROLL(8)
         for (int q = 0; q < J * 3; ++q) {
           const float w = joint_block_weighted ? jw[q / 3] : 1.0f;
           acc += (w * sh.P[q * S1 + 1 + i]) * sh.P[q * S1 + 1 + jj];
         }
       } else if (e < NG + S) {
         const int i = e - NG;
+        SF_UNROLL(8)
         for (int q = 0; q < J * 3; ++q) {
           const float w = joint_block_weighted ? jw[q / 3] : 1.0f;
           acc += (w * sh.P[q * S1 + 1 + i]) * (sh.tj[q] - sh.P[q * S1]);
         }
       } else if (e < NG + 4 * S) {
         const int c = (e - NG - S) / S, i = (e - NG - S) % S;
+        SF_UNROLL(8)
         for (int j = 0; j < J; ++j) {
           const float w = joint_block_weighted ? jw[j] : 1.0f;
           acc += w * sh.P[(j * 3 + c) * S1 + 1 + i];
