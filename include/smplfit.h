@@ -302,6 +302,26 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
                             void* workspace, size_t workspace_bytes, void* hip_stream,
                             float* avg_ms);
 
+/* Test hook: the rotation primitives of the joint-level kernels, evaluated ON THE DEVICE (the
+ * arithmetic that ships: hardware rsq / rcp seeds + Newton steps inside proj_SO3), one element per
+ * thread, so that the reference's primitive goldens incl. the degenerate inputs (rank 1 / rank 2 /
+ * reflection / zero matrices, all four mat2rotvec branches, (anti)parallel vectors) are checked
+ * against the device code and not only against its host build.  Device pointers.
+ *   PROJ_SO3      a (n,3,3) -> out (n,3,3)   pt/rotation.py:100-110
+ *   ROTVEC2MAT    a (n,3)   -> out (n,3,3)   pt/rotation.py:236-258
+ *   MAT2ROTVEC    a (n,3,3) -> out (n,3)     pt/rotation.py:261-289
+ *   ALIGN_UNIT    a, b (n,3) -> out (n,3,3)  pt/rotation.py:210-224
+ *   SWING_TWIST   a = b_ref (n,3), b = [b_tgt | A] (n,12) -> out (n,3,3)  pt/bodyfitter.py:1389-1412 */
+enum smplfit_primitive_id {
+  SMPLFIT_PRIM_PROJ_SO3 = 0,
+  SMPLFIT_PRIM_ROTVEC2MAT = 1,
+  SMPLFIT_PRIM_MAT2ROTVEC = 2,
+  SMPLFIT_PRIM_ALIGN_UNIT = 3,
+  SMPLFIT_PRIM_SWING_TWIST = 4,
+};
+int smplfit_primitives_f32(int primitive_id, const float* a, const float* b, float* out, int n,
+                           void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

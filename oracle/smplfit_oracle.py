@@ -513,15 +513,17 @@ class OracleFitter:
                      else np.asarray(initial_pose_rotvecs, dt))
             f = m.forward(pose_rotvecs=pose0, shape_betas=initial_shape_betas, kid_factor=initial_kid_factor)
             G = self.fit_global_rotations(tv, tj, f['vertices'], f['joints'], vw, jw) @ f['orientations']
-            if initial_shape_betas is not None or initial_kid_factor is not None:
-                reg_ref = np.zeros((B, self.S_all), np.float64)
-                if initial_shape_betas is not None:
-                    nbg = min(np.asarray(initial_shape_betas).shape[1], m.S)
-                    reg_ref[:, :nbg] = np.asarray(initial_shape_betas)[:, :nbg]
-                if self.enable_kid and initial_kid_factor is not None:
-                    reg_ref[:, m.S] = np.asarray(initial_kid_factor).reshape(-1)
         else:
             G = self.fit_global_rotations(tv, tj, self.default_mesh[None], m.J_template[None], vw, jw)
+        # the ridge references go to EVERY shape solve whenever they are given, also an
+        # initial_kid_factor on its own, without a warm first pass (:413-414, :448-449)
+        if initial_shape_betas is not None or initial_kid_factor is not None:
+            reg_ref = np.zeros((B, self.S_all), np.float64)
+            if initial_shape_betas is not None:
+                nbg = min(np.asarray(initial_shape_betas).shape[1], m.S)
+                reg_ref[:, :nbg] = np.asarray(initial_shape_betas)[:, :nbg]
+            if self.enable_kid and initial_kid_factor is not None:
+                reg_ref[:, m.S] = np.asarray(initial_kid_factor).reshape(-1)
         stages['glob_rotmats_iter0'] = G.copy()
         for it in range(num_iter - 1):
             r = self.fit_shape(G, tv, tj, vw, jw, beta_regularizer, beta_regularizer2, kid_regularizer,

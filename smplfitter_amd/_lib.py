@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = [
     'smplfit_get_info', 'smplfit_get_table', 'smplfit_workspace_bytes', 'smplfit_fit_f32',
     'smplfit_forward_f32', 'smplfit_part_rotations_f32', 'smplfit_shape_solve_f32',
     'smplfit_shape_solve_ex_f32', 'smplfit_fit_known_shape_f32', 'smplfit_fit_warm_f32', 'smplfit_fit_ex_f32',
-    'smplfit_time_kernel_f32',
+    'smplfit_time_kernel_f32', 'smplfit_primitives_f32',
 ]  # fmt: skip
 
 _fp = C.POINTER(C.c_float)
@@ -165,6 +165,8 @@ def load():
     lib.smplfit_fit_known_shape_f32.restype = i32
     lib.smplfit_time_kernel_f32.argtypes = [vp, i32, i32, i32, vp, sz, vp, C.POINTER(C.c_float)]
     lib.smplfit_time_kernel_f32.restype = i32
+    lib.smplfit_primitives_f32.argtypes = [i32, vp, vp, vp, i32, vp]
+    lib.smplfit_primitives_f32.restype = i32
     _lib = lib
     return lib
 

@@ -33,12 +33,24 @@ def needs_build():
     return any(osp.getmtime(osp.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
+def source_id():
+    """sha256 over the sources the library is built from (12 hex digits): the build id smplfit_version()
+    reports, so that profiles can be tied to the tree they were measured on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(SOURCES + HEADERS):
+        with open(osp.join(CSRC, f), 'rb') as fh:
+            h.update(f.encode() + b'\0' + fh.read())
+    return h.hexdigest()[:12]
+
+
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return OUT
     cmd = [
         _hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-        '-Wno-unused-value',
+        '-Wno-unused-value', f'-DSMPLFIT_BUILD_ID="{source_id()}"',
         *[osp.join(CSRC, s) for s in SOURCES], '-o', OUT + '.tmp',
     ]  # fmt: skip
     if verbose:

@@ -205,7 +205,8 @@ SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
       for (int k = 0; k < 9; ++k) rp_out[rp_pos((j - 1) * 9 + k, tb.Kp)] = rel[k];
     }
   }
-  SF_FOR(k, tb.Kp - tb.P) rp_out[rp_pos(tb.P + k, tb.Kp)] = 0.f;
+  // first padding feature = 1: its posedirs row holds v_template (the GEMM's bias, see sf_tables.cpp)
+  SF_FOR(k, tb.Kp - tb.P) rp_out[rp_pos(tb.P + k, tb.Kp)] = k == 0 ? 1.f : 0.f;
   SF_FOR(k, 3 * S1) sh.P[k] = tb.j_ext[k];
   cx.sync();
   // level-batched FK of positions and their beta-Jacobian (:892-907)
@@ -866,7 +867,8 @@ SF_HD void forward_joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch&
       for (int k = 0; k < 9; ++k) rp_out[rp_pos((j - 1) * 9 + k, tb.Kp)] = rel[k];
     }
   }
-  SF_FOR(k, tb.Kp - tb.P) rp_out[rp_pos(tb.P + k, tb.Kp)] = 0.f;
+  // first padding feature = 1: its posedirs row holds v_template (the GEMM's bias, see sf_tables.cpp)
+  SF_FOR(k, tb.Kp - tb.P) rp_out[rp_pos(tb.P + k, tb.Kp)] = k == 0 ? 1.f : 0.f;
   cx.sync();
   SF_FOR(c, 3) sh.pos[c] = sh.aux[c];
   cx.sync();

@@ -51,7 +51,9 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
   // tile when those kernels apply: measured at B = 16384, 1024 vertices 4.58 -> 4.79 M fits/s, 2048
   // vertices 3.10 -> 3.69 M (512: the wave-per-instance kernels stay ahead, 5.85 vs 5.65 M).
   if (t.Vp == V && S == 10 && V >= 1024) t.Vp += kVertexPad;
-  t.Kp = round_up(t.P, kGemmKPad);
+  // at least one padding row: row P of posedirs holds v_template and the matching pose feature is 1, so
+  // the GEMM needs no bias operand (and adds the template last, as the reference does, bodyfitter.py:913-916)
+  t.Kp = round_up(t.P + 1, kGemmKPad);
   t.smpl_family = d.is_smpl_family != 0;
   if (t.smpl_family && J < 12) return "smplfit_create: smpl-family model with < 12 joints";
 
@@ -225,12 +227,12 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
         t.pdT[(size_t)kpos(p) * 3 * Vp + (size_t)c * Vp + i] = pd[p];
         if (p % 9 == 0 || p % 9 == 4 || p % 9 == 8) acc += pd[p];
       }
+      t.pdT[(size_t)kpos(P) * 3 * Vp + (size_t)c * Vp + i] = vtc;  // bias row (feature P == 1)
       t.dm[(size_t)c * Vp + i] = wsum * acc;
       for (int s = 0; s < S; ++s)
         t.sd[(size_t)(c * S + s) * Vp + i] = shapedirs[((size_t)v * 3 + c) * S + s];
     }
   }
-  t.vtN = t.vt;
   {
     const int N = 3 * Vp, Kp = t.Kp, ntile = N / 32;
     t.pdSw.assign((size_t)ntile * 32 * Kp, 0.f);

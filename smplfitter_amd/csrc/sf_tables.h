@@ -69,9 +69,8 @@ struct HostTables {
   std::vector<float> sd;        // (3*S,Vp) shapedirs, row index c*S+s
   std::vector<uint32_t> widx;   // (KW/4, Vp) 4 joint ids per word, byte k = k-th pair
   std::vector<float> wval;      // (KW, Vp)
-  std::vector<float> pdT;       // (Kp, 3*Vp) posedirs, K-major, rows in rp_pos() (parity-major) order
+  std::vector<float> pdT;       // (Kp, 3*Vp) posedirs, K-major, rows in rp_pos() (parity-major) order; row rp_pos(P) = v_template
   std::vector<float> pdSw;      // (3*Vp/32, 32, Kp) the same, transposed per 32-column tile (A-stationary GEMM)
-  std::vector<float> vtN;       // (3*Vp) v_template in GEMM column order (== vt flattened)
   // per-vertex constants packed per 64-vertex tile for cooperative staging through LDS:
   // cstride() floats per vertex = [shapedirs s-major (s*3+c), 3*S | KW weights | KW/4 index words | pad]
   std::vector<float> cpackA;    // (Vp/64, 64, cstride) dense tiles of sorted slots  (shape accumulate)

@@ -59,7 +59,7 @@ struct DevModel {
   const int32_t* perm;      // (Vp)
   const int32_t* segments;  // (nseg,3)
   const int32_t* part_seg_start;  // (J+1) first segment of each part (empty range: unused part)
-  const float *vt, *dm, *sd, *wval, *pdT, *pdSw, *vtN, *j_template, *cpackA, *cpackB, *gblob;
+  const float *vt, *dm, *sd, *wval, *pdSw, *j_template, *cpackA, *cpackB, *gblob;
   const int32_t* gtiles;  // (ngt,3) start, count, part
   int ngt;
   const uint32_t* widx;
@@ -371,18 +371,18 @@ int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, b
     const size_t lds = (size_t)2 * 32 * (2 * NK2 + 4) * 4;
     if (transposed)
       hipLaunchKernelGGL((k_posedirs_gemm_as<NK2, true>), dim3(nchunk, Mp / 128), dim3(256), lds, st,
-                         ws.rp, d.pdSw, d.vtN, ws.vpT, N, per, Mp);
+                         ws.rp, d.pdSw, ws.vpT, N, per, Mp);
     else
       hipLaunchKernelGGL((k_posedirs_gemm_as<NK2, false>), dim3(nchunk, Mp / 128), dim3(256), lds, st,
-                         ws.rp, d.pdSw, d.vtN, ws.vposed, N, per, Mp);
+                         ws.rp, d.pdSw, ws.vposed, N, per, Mp);
     return 0;
   }
   if (transposed)
-    hipLaunchKernelGGL(k_posedirs_gemm<true>, dim3((N / 128) * (Mp / 128)), dim3(256), 0, st, ws.rp, d.pdT,
-                       d.vtN, ws.vpT, Mp, N, d.Kp);
+    hipLaunchKernelGGL(k_posedirs_gemm<true>, dim3((N / 128) * (Mp / 128)), dim3(256), 0, st, ws.rp, d.pdSw,
+                       ws.vpT, Mp, N, d.Kp);
   else
-    hipLaunchKernelGGL(k_posedirs_gemm<false>, dim3((N / 128) * (Mp / 128)), dim3(256), 0, st, ws.rp, d.pdT,
-                       d.vtN, ws.vposed, Mp, N, d.Kp);
+    hipLaunchKernelGGL(k_posedirs_gemm<false>, dim3((N / 128) * (Mp / 128)), dim3(256), 0, st, ws.rp, d.pdSw,
+                       ws.vposed, Mp, N, d.Kp);
   return 0;
 }
 
@@ -498,11 +498,15 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   ja.do_prologue = o.rotations_only ? 0 : 1;
   ja.fit_rotations = 1;
   ja.Gprev = nullptr;
+  // bodyfitter.py:363-382: the first rotation pass runs against the posed model only when a pose or a
+  // shape is given; the ridge references reach EVERY shape solve whenever they are given — also an
+  // initial_kid_factor on its own (:413-414, :448-449)
   const bool warm = o.init_pose || o.init_betas;
-  const int use_ref = (warm && (o.init_betas || o.init_kid)) ? 1 : 0;
-  if (warm) {
+  const int use_ref = (o.init_betas || o.init_kid) ? 1 : 0;
+  if (warm || use_ref)
     hipLaunchKernelGGL(k_fill_shape, dim3((B + 255) / 256), dim3(256), 0, st, ws, B, d.S, d.jt.n_kid,
                        o.init_betas, std::min(o.init_nb, d.S - d.jt.n_kid), o.init_kid);
+  if (warm) {
     ForwardArgs fa{};
     fa.pose = o.init_pose;
     fa.betas = ws.beta;  // (B,S) incl. the kid column
@@ -735,7 +739,10 @@ size_t chunked_workspace_bytes(const sf::HostTables& t, int batch) {
 extern "C" {
 
 const char* smplfit_last_error(void) { return g_last_error.c_str(); }
-const char* smplfit_version(void) { return "smplfit-hip 0.1 (gfx950)"; }
+#ifndef SMPLFIT_BUILD_ID
+#define SMPLFIT_BUILD_ID "unknown"
+#endif
+const char* smplfit_version(void) { return "smplfit-hip 0.2 (gfx950) build " SMPLFIT_BUILD_ID; }
 
 int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** out) {
   if (!desc || !out) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_create: null argument");
@@ -791,9 +798,7 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
   up(t.sd, &d.sd);
   up(t.wval, &d.wval);
   up(t.widx, &d.widx);
-  up(t.pdT, &d.pdT);
   up(t.pdSw, &d.pdSw);
-  up(t.vtN, &d.vtN);
   up(t.cpackA, &d.cpackA);
   up(t.cpackB, &d.cpackB);
   up(t.gblob, &d.gblob);
@@ -1344,6 +1349,19 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   *avg_ms = ms / (float)reps;
+  return post_launch_check();
+}
+
+int smplfit_primitives_f32(int primitive_id, const float* a, const float* b, float* out, int n,
+                           void* hip_stream) {
+  if (!a || !out || n < 0) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_primitives_f32: null pointer / negative n");
+  if (primitive_id < SMPLFIT_PRIM_PROJ_SO3 || primitive_id > SMPLFIT_PRIM_SWING_TWIST)
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_primitives_f32: unknown primitive id");
+  if ((primitive_id == SMPLFIT_PRIM_ALIGN_UNIT || primitive_id == SMPLFIT_PRIM_SWING_TWIST) && !b)
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_primitives_f32: this primitive takes two inputs");
+  if (n == 0) return SMPLFIT_OK;
+  hipLaunchKernelGGL(k_primitives, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)hip_stream, primitive_id, a, b,
+                     out, n);
   return post_launch_check();
 }
 

@@ -15,11 +15,9 @@ import torch
 from .bodymodel import BodyModel
 from .bodyfitter import BodyFitter
 from .bodyconverter import BodyConverter
-from .bodyflipper import BodyFlipper
 from . import ops  # noqa: F401  (registers torch.ops.smplfitter_amd.fit / .forward)
 
-__all__ = ['BodyModel', 'BodyFitter', 'BodyConverter', 'BodyFlipper', 'get_cached_body_model',
-           'get_cached_fit_fn']
+__all__ = ['BodyModel', 'BodyFitter', 'BodyConverter', 'get_cached_body_model', 'get_cached_fit_fn']
 
 
 @functools.lru_cache()

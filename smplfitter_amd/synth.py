@@ -124,7 +124,14 @@ def _dist_to_segments(pts, seg):
 
 def make_model_arrays(kind='smpl', seed=0, num_vertices=None, num_betas=10, shuffle=True):
     """Build the raw arrays of a synthetic SMPL-shaped ('smpl', 24 joints) or SMPL-X-shaped
-    ('smplx', 55 joints) model.  Returns a dict with the reference's on-disk keys."""
+    ('smplx', 55 joints) model.  Returns a dict with the reference's on-disk keys.
+
+    'smplx_fat' is the SMPL-X-shaped model with FAT fingers / face parts (3.5 cm instead of 1.2 cm): the
+    bone parts' twist about the bone axis is recovered from the vertices' off-axis spread
+    (pt/bodyfitter.py:1398-1410), so thin parts make pose_rotvecs ill-conditioned in the reference itself;
+    on the fat variant a tight pose_rotvecs comparison is meaningful."""
+    fat = kind.endswith('_fat')
+    kind = kind[:-4] if fat else kind
     rs = np.random.RandomState(seed)
     if kind == 'smpl':
         parents = list(SMPL_PARENTS)
@@ -152,7 +159,7 @@ def make_model_arrays(kind='smpl', seed=0, num_vertices=None, num_betas=10, shuf
     if kind == 'smpl':
         radius[22:] = 0.035
     else:
-        radius[22:] = 0.012
+        radius[22:] = 0.035 if fat else 0.012
 
     # vertices: ~V/J per part, a few more on big parts
     share = radius ** 0.5
@@ -229,7 +236,7 @@ def write_model_files(root, kind='smpl', seed=0, num_vertices=None):
     File names follow the reference loader (src/smplfitter/common.py:266-283)."""
     arrs = make_model_arrays(kind, seed, num_vertices)
     kid = arrs.pop('kid_template')
-    d = osp.join(root, kind)
+    d = osp.join(root, kind)  # 'smplx_fat' lives in its own directory, same official file name
     os.makedirs(d, exist_ok=True)
     if kind == 'smpl':
         path = osp.join(d, 'basicmodel_neutral_lbs_10_207_0_v1.1.0.pkl')

@@ -152,7 +152,7 @@ struct Emu {
     const int N = 3 * t.Vp;
     for (int b = 0; b < B; ++b)
       for (int n = 0; n < N; ++n) {
-        float acc = t.vtN[n];
+        float acc = 0.f;  // the template comes in through the padding row of posedirs
         for (int k = 0; k < t.Kp; ++k) acc = fmaf(rp[(size_t)b * t.Kp + k], t.pdT[(size_t)k * N + n], acc);
         vposed[(size_t)b * N + n] = acc;
       }
@@ -334,7 +334,7 @@ int fit_impl(const sf::HostTables& t, const float* tv, const float* tj, const fl
     rj0 = jtemplate;
   }
   const bool warm = w.pose || w.betas;
-  if (warm) {
+  if (warm || w.kid) {  // k_fill_shape: the ridge reference also for an initial_kid_factor on its own
     const int nbe = std::min(w.nb, S - t.n_kid);
     for (int b = 0; b < B; ++b) {
       for (int s = 0; s < S - t.n_kid; ++s)
@@ -343,6 +343,8 @@ int fit_impl(const sf::HostTables& t, const float* tv, const float* tj, const fl
       for (int c = 0; c < 3; ++c) e.trans[(size_t)b * 3 + c] = 0.f;
     }
     if (w.betas || w.kid) e.regref = e.beta;
+  }
+  if (warm) {
     HostCtx cx;
     for (int b = 0; b < B; ++b) {
       sf::forward_joint_stage(cx, e.jt, e.sh, w.pose ? w.pose + (size_t)b * t.J * 3 : nullptr, nullptr,

@@ -111,29 +111,6 @@ def test_create_rejects_bad_models(lib, model_root):
         _lib.Handle(desc, host_only=True)
 
 
-@pytest.mark.parametrize('name', ['smpl', 'smplx'])
-def test_flipper_host_tables(name, model_root, data_root, golden, monkeypatch):
-    """Host-side pieces of BodyFlipper against the reference's fixture: the mirror matrix (for SMPL the
-    product smplx2smpl @ mirror @ smpl2smplx, pt/bodyflipper.py:136-154) and the joint permutation
-    from the optimal assignment (:129-133)."""
-    import torch
-
-    from smplfitter_amd.pt import bodyflipper as BF
-
-    monkeypatch.setenv('DATA_ROOT', data_root)
-    g, ge = golden(name), golden(f'ext_{name}')
-    kind, md = util.load_md(model_root, name, g)
-    csr = BF.get_mirror_csr(md.num_vertices)
-    v = torch.from_numpy(g['target_vertices']).permute(1, 0, 2).reshape(md.num_vertices, -1)
-    r = torch.sparse.mm(csr, v).reshape(md.num_vertices, -1, 3).permute(1, 0, 2) * torch.tensor([-1.0, 1, 1])
-    assert np.abs(r.numpy()[:, ::50] - ge['flip.vertices_sub']).max() < 2e-6
-    om, _ = util.make_oracle(md, kind)
-    rest = om.forward(np.zeros((1, 3 * md.num_joints), np.float32), np.zeros((1, 0), np.float32))['joints'][0]
-    perm = BF.get_mirror_mapping(torch.from_numpy(rest)).numpy()
-    assert (perm == ge['flip.mirror_inds_joints']).all()
-    assert sorted(perm.tolist()) == list(range(md.num_joints))
-
-
 def test_torch_library_operators_registered(model_root):
     """`smplfitter_amd::fit` / `::forward` exist with shape functions: under FakeTensorMode (what
     torch.compile / export trace with) they return the result shapes without touching a GPU."""

@@ -76,7 +76,12 @@ def test_fit_goldens(name, model_root, golden, dev, vertex_path):
     kind, md = util.load_md(model_root, name, g)
     om64, _ = util.make_oracle(md, kind, np.float64)
     m, f = get_model(model_root, name, g, dev)
-    pose_tol = 5e-3 if name == 'smplx' else 1.5e-3
+    # pose: 3e-4 on the well-conditioned SMPL fixtures (the host emulation of this arithmetic sits at
+    # <= 2.2e-4 on all 32 option combinations; the reference's own fp32 floor is 3e-4); the
+    # thin-finger SMPL-X fixture is ill-conditioned in the reference itself (pt vs fp64: 5e-4) and is judged
+    # on vertices (its fat-part twin is gated in test_gpu_evidence.py::test_parity_statistics)
+    pose_tol = 5e-3 if name == 'smplx' else 3e-4
+    beta_tol = 3e-4 if name == 'smplx' else 1e-4
     for c in util.fit_configs(g):
         cfg = util.cfg_from_name(c)
         if not cfg['joints'] and name == 'smpl1024':
@@ -91,7 +96,7 @@ def test_fit_goldens(name, model_root, golden, dev, vertex_path):
         ))
         ref = {k: g[f'fit.{c}.{k}'] for k in ('pose_rotvecs', 'shape_betas', 'trans', 'orientations')}
         assert util.vertex_l2(om64, o, ref) < 1e-4, c
-        assert np.abs(o['shape_betas'] - ref['shape_betas']).max() < 3e-4, c
+        assert np.abs(o['shape_betas'] - ref['shape_betas']).max() < beta_tol, c
         assert np.abs(o['trans'] - ref['trans']).max() < 1e-5, c
         assert np.abs(o['pose_rotvecs'] - ref['pose_rotvecs']).max() < pose_tol, c
         assert np.abs(o['orientations'] - ref['orientations']).max() < pose_tol, c
@@ -397,36 +402,6 @@ def test_warm_start_goldens(name, model_root, golden, dev):
     b = to_np(f.fit(t(g['target_vertices'], dev), t(g['target_joints'], dev), num_iter=2,
                     initial_pose_rotvecs=None, initial_shape_betas=None))
     assert all(np.array_equal(a[k], b[k]) for k in a)
-
-
-@pytest.mark.parametrize('name', ['smpl', 'smplx'])
-def test_body_flipper(name, model_root, data_root, golden, dev, monkeypatch):
-    """BodyFlipper.flip end to end (forward -> mirror matrix -> warm-started kid fit) against the
-    reference run on the same synthetic mirror / transfer files."""
-    from smplfitter_amd.pt import BodyFlipper
-
-    monkeypatch.setenv('DATA_ROOT', data_root)
-    g, ge = golden(name), golden(f'ext_{name}')
-    kind, md = util.load_md(model_root, name, g)
-    om, _ = util.make_oracle(md, kind, np.float64)
-    m, _ = get_model(model_root, name, g, dev)
-    fl = BodyFlipper(m)
-    assert (fl.mirror_inds_joints.cpu().numpy() == ge['flip.mirror_inds_joints']).all()
-    fv = fl.flip_vertices(t(g['target_vertices'], dev)).cpu().numpy()
-    assert np.abs(fv[:, ::50] - ge['flip.vertices_sub']).max() < 2e-6
-    nr = fl.naive_flip_rotvecs(t(g['pose'], dev)).cpu().numpy()
-    assert np.abs(nr - ge['flip.naive_rotvecs']).max() == 0
-    for tag, kid, ni in (('a', None, 1), ('b', None, 3), ('c', g['kid'], 2)):
-        r = fl.flip(t(g['pose'], dev), t(g['betas'], dev), t(g['trans'], dev),
-                    kid_factor=None if kid is None else t(kid, dev), num_iter=ni)
-        assert r['kid_factor'] is not None  # the kid fitter always reports it (pinned to ~0 without input)
-        o = {k: v.cpu().numpy() for k, v in r.items() if v is not None}
-        ref = {k: ge[f'flip.{tag}.{k}'] for k in ('pose_rotvecs', 'shape_betas', 'trans', 'kid_factor')}
-        va = om.forward(o['pose_rotvecs'], o['shape_betas'], o['trans'], kid_factor=o['kid_factor'])['vertices']
-        vb = om.forward(ref['pose_rotvecs'], ref['shape_betas'], ref['trans'], kid_factor=ref['kid_factor'])['vertices']
-        assert np.linalg.norm(va - vb, axis=-1).max() < 1e-4, tag
-        assert np.abs(o['trans'] - ref['trans']).max() < 2e-5, tag
-        assert np.abs(o['shape_betas'] - ref['shape_betas']).max() < 1e-3, tag
 
 
 def test_torch_compile_through_operators(model_root, golden, dev):

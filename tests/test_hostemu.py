@@ -51,12 +51,14 @@ def test_forward(name, model_root, golden):
     assert np.abs(fw2['vertices'] - g['target_vertices']).max() < 5e-6
 
 
-@pytest.mark.parametrize('name', ['smpl', 'smplx', 'smpl1024'])
+@pytest.mark.parametrize('name', ['smpl', 'smplx', 'smpl1024', 'smplxfat'])
 def test_fit_goldens(name, model_root, golden):
     g = golden(name)
     kind, md = util.load_md(model_root, name, g)
     om64, of64 = util.make_oracle(md, kind, np.float64)
-    pose_tol = 5e-3 if name == 'smplx' else 1.5e-3
+    # 3e-4 on the well-conditioned fixtures (SMPL, fat-part SMPL-X); the thin-finger SMPL-X one is
+    # ill-conditioned in the reference itself and is judged on vertices
+    pose_tol = 5e-3 if name == 'smplx' else (3e-4 if name in ('smpl', 'smplxfat') else 1.5e-3)
     G0 = None
     for c in util.fit_configs(g):
         cfg = util.cfg_from_name(c)
@@ -77,7 +79,8 @@ def test_fit_goldens(name, model_root, golden):
         assert np.abs(o['orientations'] - ref['orientations']).max() < pose_tol, c
         if cfg['joints'] and not cfg['weights']:
             G0 = o['glob_rotmats_iter0']
-    assert np.abs(G0 - g['stage.glob_rotmats_iter0']).max() < (2e-3 if name == 'smplx' else 5e-4)
+    if 'stage.glob_rotmats_iter0' in g:
+        assert np.abs(G0 - g['stage.glob_rotmats_iter0']).max() < (2e-3 if name == 'smplx' else 5e-4)
 
 
 @pytest.mark.parametrize('name', ['smpl'])

@@ -19,7 +19,19 @@ def load_md(root, name, g=None):
     kw = {}
     if g is not None and 'vertex_subset' in g:
         kw['vertex_subset'] = g['vertex_subset']
-    return kind, modelio.load_model(kind, 'neutral', model_root=f'{root}/{kind}', num_betas=10, **kw)
+    return kind, modelio.load_model(kind, 'neutral', model_root=f'{root}/{model_dir(name)}', num_betas=10, **kw)
+
+
+def model_dir(name):
+    """Directory of golden set ``name`` under the synthetic model root (smplxfat: the fat-part SMPL-X
+    variant of synth.make_model_arrays('smplx_fat'), its own directory, the official SMPL-X file name)."""
+    return 'smplx_fat' if name == 'smplxfat' else ('smplx' if name.startswith('smplx') else 'smpl')
+
+
+def stats(a, b):
+    """max / p99 / median of |a - b| (SURVEY.md §8d asks for all three on pose_rotvecs)."""
+    d = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).reshape(-1)
+    return dict(max=float(d.max()), p99=float(np.percentile(d, 99)), median=float(np.median(d)))
 
 
 def make_oracle(md, kind, dtype=np.float32):
@@ -112,6 +124,8 @@ WARM_CASES = {
                             final_adjust_rots=True, kid_regularizer=1e9), ('pose', 'betas')),
     'd': (True, True, dict(num_iter=3, beta_regularizer=2.0, kid_regularizer=0.5), ('pose', 'betas', 'kid')),
     'e': (False, True, dict(num_iter=1, beta_regularizer=5.0, final_adjust_rots=False), ('betas',)),
+    # initial_kid_factor ALONE: no warm first pass, but the kid ridge still pulls towards it (:413-414)
+    'f': (True, True, dict(num_iter=2, beta_regularizer=1.0, kid_regularizer=0.7), ('kid',)),
 }
 
 
