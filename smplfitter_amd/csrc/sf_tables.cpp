@@ -241,6 +241,38 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
         for (int k = 0; k < Kp; ++k)
           t.pdSw[((size_t)nt * 32 + n) * Kp + k] = t.pdT[(size_t)k * N + nt * 32 + n];
   }
+  t.pdB.clear();
+  if (t.Kp == 208) {  // split-bf16 planes for k_posedirs_gemm_bf16x3 (error-free 3-way split of every fp32)
+    const int N = 3 * Vp, Kp = t.Kp, ntile = N / 32, nslot = Kp / 8;
+    auto bf16_rne = [](float x) -> uint16_t {
+      uint32_t u;
+      std::memcpy(&u, &x, 4);
+      u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even (finite inputs)
+      return (uint16_t)(u >> 16);
+    };
+    auto bf16_f32 = [](uint16_t h) -> float {
+      const uint32_t u = (uint32_t)h << 16;
+      float f;
+      std::memcpy(&f, &u, 4);
+      return f;
+    };
+    t.pdB.assign((size_t)ntile * 3 * 32 * Kp, 0);
+    for (int nt = 0; nt < ntile; ++nt)
+      for (int n = 0; n < 32; ++n)
+        for (int k = 0; k < Kp; ++k) {
+          const float x = t.pdSw[((size_t)nt * 32 + n) * Kp + k];
+          const uint16_t h = bf16_rne(x);
+          const float r1 = x - bf16_f32(h);
+          const uint16_t m = bf16_rne(r1);
+          const uint16_t l = bf16_rne(r1 - bf16_f32(m));
+          const int slot = (k >> 3) ^ ((n >> 3) & 1);
+          const size_t base = (((size_t)nt * 3) * 32 + n) * Kp + (size_t)slot * 8 + (k & 7);
+          t.pdB[base] = h;
+          t.pdB[base + (size_t)32 * Kp] = m;
+          t.pdB[base + (size_t)64 * Kp] = l;
+        }
+    (void)nslot;
+  }
   {
     const int cs = t.cstride();
     auto pack = [&](float* dst, int slot) {  // one vertex record

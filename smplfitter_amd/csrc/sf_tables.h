@@ -71,6 +71,11 @@ struct HostTables {
   std::vector<float> wval;      // (KW, Vp)
   std::vector<float> pdT;       // (Kp, 3*Vp) posedirs, K-major, rows in rp_pos() (parity-major) order; row rp_pos(P) = v_template
   std::vector<float> pdSw;      // (3*Vp/32, 32, Kp) the same, transposed per 32-column tile (A-stationary GEMM)
+  // Split-bf16 image of pdSw for the matrix-core GEMM (Kp == 208 only): per 32-column tile three planes
+  // (hi, mid, lo with hi + mid + lo == the fp32 value, each rounded to nearest bf16) of [32 n][26 slots][8 k],
+  // slot = k / 8 with bit 0 flipped for rows with (n >> 3) & 1 (bank-conflict-free 16-byte LDS reads from
+  // unpadded 416-byte rows).  The tile image is copied to LDS verbatim.
+  std::vector<uint16_t> pdB;
   // per-vertex constants packed per 64-vertex tile for cooperative staging through LDS:
   // cstride() floats per vertex = [shapedirs s-major (s*3+c), 3*S | KW weights | KW/4 index words | pad]
   std::vector<float> cpackA;    // (Vp/64, 64, cstride) dense tiles of sorted slots  (shape accumulate)

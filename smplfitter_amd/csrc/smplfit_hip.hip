@@ -60,6 +60,7 @@ struct DevModel {
   const int32_t* segments;  // (nseg,3)
   const int32_t* part_seg_start;  // (J+1) first segment of each part (empty range: unused part)
   const float *vt, *dm, *sd, *wval, *pdSw, *j_template, *cpackA, *cpackB, *gblob;
+  const uint16_t* pdB;  // split-bf16 tile images of posedirs (Kp == 208), see HostTables::pdB
   const int32_t* gtiles;  // (ngt,3) start, count, part
   int ngt;
   const uint32_t* widx;
@@ -358,8 +359,42 @@ int check_common(const smplfit_handle* h, int batch, void* workspace, size_t wor
   return 0;
 }
 
+// Arithmetic of the posedirs contraction (SMPL, Kp == 208): "bf16x3" (default) runs it on the bf16 matrix
+// cores with every fp32 operand split error-free into three bf16 terms (6 products per k, fp32 accumulate:
+// fp32-equivalent accuracy, see k_posedirs_gemm_bf16x3); "f32" (SMPLFIT_GEMM=f32) uses the fp32 MFMA, which
+// on gfx950 shares the vector ALUs with ordinary VALU work.  Read at every launch (tests switch it).
+bool gemm_bf16x3() {
+  const char* e = getenv("SMPLFIT_GEMM");
+  return !(e && e[0] == 'f');
+}
+
 int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, bool transposed = false) {
   const int Mp = (int)align_up((size_t)B, 128), N = 3 * d.Vp;
+  if (d.Kp == 208 && gemm_bf16x3()) {
+    // one workgroup = 8 waves = 256 instances and a whole CU (see k_posedirs_gemm_bf16x3); ~3 workgroups per CU
+    const int ntiles = N / 32, ny = (Mp + 32 * kGemmWaves - 1) / (32 * kGemmWaves);
+    int nchunk = std::max(1, (3 * 256 + ny - 1) / ny);
+    nchunk = std::min(nchunk, ntiles);
+    const int per = (ntiles + nchunk - 1) / nchunk;
+    nchunk = (ntiles + per - 1) / per;
+    const size_t lds = (size_t)2 * kGemmTileBytes;
+    static std::once_flag once[16];
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    std::call_once(once[dev_id & 15], [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_posedirs_gemm_bf16x3<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_posedirs_gemm_bf16x3<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (transposed)
+      hipLaunchKernelGGL((k_posedirs_gemm_bf16x3<true>), dim3(nchunk, ny), dim3(64 * kGemmWaves), lds, st, ws.rp,
+                         d.pdB, ws.vpT, N, per, Mp);
+    else
+      hipLaunchKernelGGL((k_posedirs_gemm_bf16x3<false>), dim3(nchunk, ny), dim3(64 * kGemmWaves), lds, st, ws.rp,
+                         d.pdB, ws.vposed, N, per, Mp);
+    return 0;
+  }
   if (d.Kp == 208) {  // SMPL (J = 24): A-stationary kernel, 104 A registers per lane
     constexpr int NK2 = 104;
     const int ntiles = N / 32;
@@ -368,7 +403,24 @@ int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, b
     nchunk = std::min(nchunk, ntiles);
     const int per = (ntiles + nchunk - 1) / nchunk;
     nchunk = (ntiles + per - 1) / per;
-    const size_t lds = (size_t)2 * 32 * (2 * NK2 + 4) * 4;
+    size_t lds = (size_t)2 * 32 * (2 * NK2 + 4) * 4;
+    {
+      // SMPLFIT_GEMM_LDS_KB: pad the workgroup's LDS request (84 = one GEMM workgroup per CU, which leaves
+      // LDS and registers for two batch-major workgroups of another chunk beside it)
+      static const int pad_kb = [] { const char* e = getenv("SMPLFIT_GEMM_LDS_KB"); return e ? atoi(e) : 0; }();
+      if (pad_kb > 0) {
+        lds = std::max(lds, (size_t)pad_kb * 1024);
+        static std::once_flag once[16];
+        int dev_id = 0;
+        (void)hipGetDevice(&dev_id);
+        std::call_once(once[dev_id & 15], [] {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_posedirs_gemm_as<NK2, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_posedirs_gemm_as<NK2, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        });
+      }
+    }
     if (transposed)
       hipLaunchKernelGGL((k_posedirs_gemm_as<NK2, true>), dim3(nchunk, Mp / 128), dim3(256), lds, st,
                          ws.rp, d.pdSw, ws.vpT, N, per, Mp);
@@ -799,6 +851,7 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
   up(t.wval, &d.wval);
   up(t.widx, &d.widx);
   up(t.pdSw, &d.pdSw);
+  up(t.pdB, &d.pdB);
   up(t.cpackA, &d.cpackA);
   up(t.cpackB, &d.cpackB);
   up(t.gblob, &d.gblob);
