@@ -1118,19 +1118,27 @@ int smplfit_fit_ex_f32(const smplfit_handle* h, const smplfit_fit_args* args) {
   std::lock_guard<std::mutex> lock(h->mu);
   SF_HIP_TRY(hipEventRecord(h->ev_fork, st));
   char* wsp = (char*)workspace;
-  int b0 = 0;
+  int b0 = 0, first_error = 0;
+  std::string first_msg;
   for (int c = 0; c < nchunk; ++c) {
     hipStream_t cs = c == 0 ? st : h->side[c - 1];
     if (c > 0) SF_HIP_TRY(hipStreamWaitEvent(cs, h->ev_fork, 0));
     rc = run_chunk(b0, sizes[c], wsp, cs);
-    if (rc) return rc;
-    if (c > 0) {
-      SF_HIP_TRY(hipEventRecord(h->ev_join[c - 1], cs));
-      SF_HIP_TRY(hipStreamWaitEvent(st, h->ev_join[c - 1], 0));
+    if (rc && !first_error) {
+      first_error = rc;
+      first_msg = g_last_error;
     }
+    // a chunk that was forked is always joined back, also after an error: an unjoined fork would
+    // invalidate a stream capture and leave work in flight that the caller's stream does not wait for
+    if (c > 0) {
+      (void)hipEventRecord(h->ev_join[c - 1], cs);
+      (void)hipStreamWaitEvent(st, h->ev_join[c - 1], 0);
+    }
+    if (first_error) break;
     wsp += carve(h->t, sizes[c], nullptr, nullptr);
     b0 += sizes[c];
   }
+  if (first_error) return fail(first_error, first_msg);
   return SMPLFIT_OK;
 }
 
