@@ -371,12 +371,16 @@ bool gemm_bf16x3() {
 int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, bool transposed = false) {
   const int Mp = (int)align_up((size_t)B, 128), N = 3 * d.Vp;
   if (d.Kp == 208 && gemm_bf16x3()) {
-    // one workgroup = 8 waves = 256 instances and a whole CU (see k_posedirs_gemm_bf16x3); ~3 workgroups per CU
+    // Workgroup = 8 waves x 32 instances = one whole CU (see k_posedirs_gemm_bf16x3).  XCD-aware tiling: block
+    // id = y * nchunk + x runs on XCD id % 8, so with nchunk a multiple of 8 a tile chunk x lives on ONE XCD,
+    // and with nchunk * ny ~ 512 (two residency rounds) the instance blocks y of a chunk walk its tiles
+    // together: the 39 KB tile images come out of that XCD's L2 and posedirs is fetched from HBM about twice
+    // per launch instead of once per instance block (FETCH_SIZE: 444 -> 72 MB per launch at B = 4096).
     const int ntiles = N / 32, ny = (Mp + 32 * kGemmWaves - 1) / (32 * kGemmWaves);
-    int nchunk = std::max(1, (3 * 256 + ny - 1) / ny);
+    int nchunk = std::max(8, (2 * 256 / ny + 4) / 8 * 8);
+    if (const char* e = getenv("SMPLFIT_GEMM_NCHUNK")) nchunk = std::max(1, atoi(e));
     nchunk = std::min(nchunk, ntiles);
-    const int per = (ntiles + nchunk - 1) / nchunk;
-    nchunk = (ntiles + per - 1) / per;
+    const int per = (ntiles + nchunk - 1) / nchunk;  // trailing chunks may be empty (they return at once)
     const size_t lds = (size_t)2 * kGemmTileBytes;
     static std::once_flag once[16];
     int dev_id = 0;

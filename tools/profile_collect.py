@@ -1,0 +1,99 @@
+"""Turn the raw rocprofv3 output of tools/profile_round.sh into the small files committed under profiles/:
+   <tag>_kernel_stats_chunks1.csv / <tag>_kernel_stats.csv  per-kernel launch statistics (from the kernel traces)
+   <tag>_trace_summary.txt                                  overlap of the chunk streams
+   pmc_traffic.json                                         HBM bytes per launch per kernel + per fit, with the build id
+   <tag>_pmc_mfma.json                                      matrix-pipe / VALU counters per kernel
+Usage: python tools/profile_collect.py gpurun_out/prof_<tag> <tag>"""
+import collections, csv, glob, json, os, re, sys
+
+src, tag = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DST = os.path.join(src, 'out')  # gpurun merges gpurun_out/ back; copy DST/* into profiles/ afterwards
+os.makedirs(DST, exist_ok=True)
+
+
+def short(n):
+    m = re.search(r'(k_[a-z_0-9]+)', n)
+    return m.group(1) if m else n.split('(')[0][:48]
+
+
+def trace_rows(d):
+    rows = []
+    for f in glob.glob(f'{d}/**/*kernel_trace.csv', recursive=True):
+        for r in csv.DictReader(open(f)):
+            rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
+    rows.sort()
+    return rows
+
+
+def stats_csv(rows, path, head):
+    t_lo = rows[0][0] + (rows[-1][1] - rows[0][0]) // 3  # steady state: skip set-up and warm-up
+    per = collections.defaultdict(list)
+    for s, e, n in rows:
+        if s >= t_lo:
+            per[short(n)].append((e - s) / 1e3)
+    tot = sum(sum(v) for v in per.values())
+    with open(path, 'w') as fh:
+        fh.write(f'# {head}\n')
+        fh.write('kernel,calls,total_us,avg_us,min_us,max_us,percent\n')
+        for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            fh.write(f'{k},{len(v)},{sum(v):.1f},{sum(v)/len(v):.2f},{min(v):.2f},{max(v):.2f},{100*sum(v)/tot:.2f}\n')
+    ev = sorted([(s, 1) for s, e, n in rows if s >= t_lo] + [(e, -1) for s, e, n in rows if s >= t_lo])
+    depth, last, b1, b2 = 0, ev[0][0], 0, 0
+    for tme, dl in ev:
+        if depth >= 1: b1 += tme - last
+        if depth >= 2: b2 += tme - last
+        depth += dl; last = tme
+    span = ev[-1][0] - ev[0][0]
+    return f'{os.path.basename(path)}: span {span/1e6:.2f} ms, kernel time summed {tot/1e3:.2f} ms, >= 1 kernel in flight {100*b1/span:.1f} %, >= 2 kernels {100*b2/span:.1f} %'
+
+
+bench = json.load(open(f'{src}/bench_default.json'))
+build = bench['build']
+head = f'rocprofv3 --kernel-trace of `python bench.py --steps 10 --warmup 3 --no-cpu-baseline`, build "{build}", git HEAD see profiles/README.md'
+lines = []
+for sub, name, extra in (('trace1', f'{tag}_kernel_stats_chunks1.csv', 'SMPLFIT_CHUNKS=1 (4096-instance launches)'),
+                         ('trace2', f'{tag}_kernel_stats.csv', 'default chunking (two 2048-instance chunks on two streams)')):
+    rows = trace_rows(f'{src}/{sub}')
+    if rows:
+        lines.append(stats_csv(rows, f'{DST}/{name}', head + '; ' + extra))
+open(f'{DST}/{tag}_trace_summary.txt', 'w').write('\n'.join(lines) + '\n')
+
+# ---- PMC: mean counter value per dispatch per kernel (steady-state dispatches of the fit only)
+def pmc(d):
+    res = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(f'{d}/**/*counter_collection.csv', recursive=True):
+        for r in csv.DictReader(open(f)):
+            res[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+    return res
+
+fetch, write = pmc(f'{src}/pmc_FETCH_SIZE'), pmc(f'{src}/pmc_WRITE_SIZE')
+B = bench['config']['batch_per_gpu']
+kern = {}
+for k in sorted(set(fetch) | set(write)):
+    if not k.startswith('k_'):
+        continue
+    f_kib = fetch[k].get('FETCH_SIZE', [0]); w_kib = write[k].get('WRITE_SIZE', [0])
+    # MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the
+    # bytes of wide coalesced streaming reads -> x2 (WRITE_SIZE uncalibrated, taken as is)
+    kern[k] = dict(bytes_per_launch=int((2 * sum(f_kib) / len(f_kib) + sum(w_kib) / len(w_kib)) * 1024),
+                   launches_in_pass=len(f_kib))
+# launches per fit (num_iter = 3) from the one-chunk trace
+rows = trace_rows(f'{src}/trace1')
+cnt = collections.Counter(short(n) for s, e, n in rows)
+fits = max(1, cnt.get('k_refine_epilogue', 1))
+per_fit = 0
+for k, v in kern.items():
+    v['launches_per_fit'] = round(cnt.get(k, 0) / fits, 2)
+    per_fit += v['bytes_per_launch'] * v['launches_per_fit']
+json.dump(dict(build=build, batch=B, config=bench['config']['name'], chunks=1,
+               note='HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB, rocprofv3 --pmc, separate passes, SMPLFIT_CHUNKS=1',
+               kernels={k: v['bytes_per_launch'] for k, v in kern.items()}, detail=kern,
+               bytes_per_fit=int(per_fit / B)), open(f'{DST}/pmc_traffic.json', 'w'), indent=1)
+m = pmc(f'{src}/pmc_MFMA')
+json.dump({k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in m.items() if k.startswith('k_')},
+          open(f'{DST}/{tag}_pmc_mfma.json', 'w'), indent=1)
+for n in ('bench_default.json', 'bench_chunks1.json'):
+    if os.path.exists(f'{src}/{n}'):
+        open(f'{DST}/{tag}_{n}', 'w').write(open(f'{src}/{n}').read())
+print('\n'.join(lines)); print('bytes per fit (PMC):', int(per_fit / B))
