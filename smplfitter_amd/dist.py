@@ -2,7 +2,7 @@
 
 The fit of every instance is independent (reference: all reductions in ``BodyFitter.fit`` are
 intra-instance unless ``share_beta``), so rank ``r`` of ``W`` fits a contiguous block of rows and the
-only communication is ONE all-gather of the packed result rows ``(B_local, 3J+S+3)`` —
+only communication is ONE all-gather of the packed result rows ``(B_local, 3J+S+3 [+ optional columns])`` —
 ``torch.distributed`` backend ``nccl`` (= RCCL over xGMI) on GPUs, ``gloo`` in the CPU tests.
 
 ``share_beta`` is the one mode with an exchange step inside the fit (reference pt/lstsq.py:24-26: the
@@ -25,17 +25,29 @@ def shard_range(total: int, rank: int, world: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def pack_results(res: dict) -> torch.Tensor:
-    """(B, 3J+S+3) rows: pose_rotvecs | shape_betas | trans."""
-    return torch.cat([res['pose_rotvecs'], res['shape_betas'], res['trans']], dim=1).contiguous()
+# result columns in packing order; the optional ones are packed when the fit returned them
+_OPTIONAL = ('kid_factor', 'scale_corr', 'orientations', 'relative_orientations')
 
 
-def unpack_results(rows: torch.Tensor, num_joints: int, num_betas: int) -> dict:
-    j3 = 3 * num_joints
-    return dict(
-        pose_rotvecs=rows[:, :j3], shape_betas=rows[:, j3:j3 + num_betas],
-        trans=rows[:, j3 + num_betas:j3 + num_betas + 3],
-    )
+def pack_results(res: dict) -> tuple[torch.Tensor, list]:
+    """Rows ``pose_rotvecs | shape_betas | trans`` followed by every optional per-instance result the fit
+    returned (``kid_factor``, ``scale_corr``, ``orientations``, ``relative_orientations``, flattened), and
+    the layout ``[(key, trailing shape), ...]`` needed to unpack them."""
+    keys = ['pose_rotvecs', 'shape_betas', 'trans'] + [k for k in _OPTIONAL if res.get(k) is not None]
+    layout = [(k, tuple(res[k].shape[1:])) for k in keys]
+    B = res['pose_rotvecs'].shape[0]
+    return torch.cat([res[k].reshape(B, -1) for k in keys], dim=1).contiguous(), layout
+
+
+def unpack_results(rows: torch.Tensor, layout: list) -> dict:
+    out, c = {}, 0
+    for key, shape in layout:
+        n = 1
+        for d in shape:
+            n *= d
+        out[key] = rows[:, c:c + n].reshape(rows.shape[0], *shape)
+        c += n
+    return out
 
 
 def gather_rows(local_rows: torch.Tensor, total: int, group=None) -> torch.Tensor:
@@ -75,5 +87,6 @@ def fit_sharded(fit_fn, target_vertices: torch.Tensor, target_joints: Optional[t
     lo, hi = shard_range(total, rank, world)
     res = fit_fn(target_vertices[lo:hi], None if target_joints is None else target_joints[lo:hi],
                  **fit_kwargs)
-    rows = gather_rows(pack_results(res), total, group)
-    return unpack_results(rows, num_joints, num_betas)
+    rows, layout = pack_results(res)  # the layout is the same on every rank (same options)
+    assert layout[0] == ('pose_rotvecs', (3 * num_joints,)) and layout[1][1] == (num_betas,), layout
+    return unpack_results(gather_rows(rows, total, group), layout)

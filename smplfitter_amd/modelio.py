@@ -78,15 +78,41 @@ class _ChumpyStandIn:
 
 
 class _ModelUnpickler(pickle.Unpickler):
+    """Restricted unpickler for body-model / deformation-transfer files: numpy array reconstruction, scipy
+    sparse matrices, chumpy stand-ins and plain builtins are allowed; every other global raises
+    ``UnpicklingError`` (a crafted model file cannot import arbitrary callables)."""
+
+        # protocol-2 pickles of numpy arrays decode their byte payload with ``_codecs.encode(str, 'latin1')``:
+    # a pure string -> bytes function, safe to allow.
+    _ALLOWED = {
+        ('_codecs', 'encode'),
+        ('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'),
+        ('numpy.core.multiarray', 'scalar'), ('numpy._core.multiarray', 'scalar'),
+        ('numpy', 'ndarray'), ('numpy', 'dtype'), ('numpy', 'matrix'),
+        ('numpy.core.numeric', '_frombuffer'), ('numpy._core.numeric', '_frombuffer'),
+        ('collections', 'OrderedDict'), ('builtins', 'dict'), ('builtins', 'list'), ('builtins', 'tuple'),
+        ('builtins', 'set'), ('builtins', 'frozenset'), ('builtins', 'slice'), ('builtins', 'complex'),
+        ('builtins', 'bytearray'), ('__builtin__', 'dict'), ('__builtin__', 'list'), ('__builtin__', 'tuple'),
+        ('__builtin__', 'set'), ('__builtin__', 'object'), ('builtins', 'object'), ('copy_reg', '_reconstructor'),
+        ('copyreg', '_reconstructor'),
+    }
+
     def find_class(self, module, name):
         if module.split('.')[0] == 'chumpy':
             return _ChumpyStandIn
-        if module.startswith('scipy.sparse.'):  # old pickles: scipy.sparse.csc.csc_matrix etc.
+        if module == 'scipy.sparse' or module.startswith('scipy.sparse.'):  # incl. old scipy.sparse.csc.csc_matrix
             import scipy.sparse
 
-            if hasattr(scipy.sparse, name):
+            if name.endswith(('_matrix', '_array')) and hasattr(scipy.sparse, name):
                 return getattr(scipy.sparse, name)
-        return super().find_class(module, name)
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f'global {module}.{name} is not allowed in a body-model file')
+
+
+def restricted_load(fileobj, **kw):
+    """``pickle.load`` through ``_ModelUnpickler`` (latin1 for the python-2 pickles SMPL ships as)."""
+    return _ModelUnpickler(fileobj, **kw).load()
 
 
 def _resolve_root(model_name, model_root):

@@ -8,13 +8,13 @@ from __future__ import annotations
 
 import os
 import os.path as osp
-import pickle
 from typing import Optional
 
 import numpy as np
 import torch
 import torch.nn as nn
 
+from .. import modelio
 from .bodyfitter import BodyFitter
 from .bodymodel import BodyModel
 
@@ -23,7 +23,7 @@ def load_vertex_converter_csr(path):
     """The official ``*_deftrafo_setup.pkl`` files hold a (V_out, 2 V_in) scipy matrix whose first
     V_in columns are the barycentric transfer (reference common.py:425-429)."""
     with open(path, 'rb') as f:
-        m = pickle.load(f)['mtx'].tocsr().astype(np.float32)
+        m = modelio.restricted_load(f, encoding='latin1')['mtx'].tocsr().astype(np.float32)
     return m[:, : m.shape[1] // 2]
 
 

@@ -19,7 +19,6 @@ import torch
 from torch.library import custom_op
 
 _models: 'weakref.WeakValueDictionary[int, torch.nn.Module]' = weakref.WeakValueDictionary()
-_fitters: dict = {}
 _ids = itertools.count(1)
 
 
@@ -41,13 +40,21 @@ def _model(model_id: int):
 
 
 def _fitter(model_id: int, enable_kid: bool):
+    """The operator's BodyFitter lives ON the model (``model._op_fitters``): no module-level strong reference
+    keeps a model and its per-device handles (19-66 MB each) alive after the user dropped it."""
     from .bodyfitter import BodyFitter
 
-    key = (model_id, enable_kid)
-    f = _fitters.get(key)
-    if f is None or f.body_model is not _model(model_id):
-        f = _fitters[key] = BodyFitter(_model(model_id), enable_kid=enable_kid)
+    m = _model(model_id)
+    cache = m.__dict__.setdefault('_op_fitters', {})
+    f = cache.get(enable_kid)
+    if f is None:
+        f = BodyFitter(m, enable_kid=enable_kid)
+        cache[enable_kid] = f
     return f
+
+
+def _model_device(model_id: int):
+    return _model(model_id).v_template.device
 
 
 @custom_op('smplfitter_amd::fit', mutates_args=())
@@ -76,7 +83,8 @@ def _(model_id, enable_kid, target_vertices, target_joints, vertex_weights, join
       initial_shape_betas, initial_kid_factor, share_beta, scale_mode, scale_regularizer):
     m = _model(model_id)
     B, J, S = target_vertices.shape[0], m.num_joints, m.num_betas
-    new = lambda *s: target_vertices.new_empty(s, dtype=torch.float32)  # noqa: E731
+    dev = _model_device(model_id)  # the real operator returns tensors on the MODEL's device
+    new = lambda *s: target_vertices.new_empty(s, dtype=torch.float32, device=dev)  # noqa: E731
     return [new(B, 3 * J), new(B, S), new(B, 3), new(B), new(B, J, 3, 3), new(B, J, 3, 3),
             new(B if scale_mode else 0)]
 
@@ -99,5 +107,6 @@ def _(model_id, pose_rotvecs, shape_betas, trans, kid_factor, rel_rotmats, glob_
     m = _model(model_id)
     first = next(a for a in (pose_rotvecs, shape_betas, trans, rel_rotmats, glob_rotmats) if a is not None)
     B, J, V = first.shape[0], m.num_joints, m.num_vertices
-    new = lambda *s: first.new_empty(s, dtype=torch.float32)  # noqa: E731
+    dev = _model_device(model_id)
+    new = lambda *s: first.new_empty(s, dtype=torch.float32, device=dev)  # noqa: E731
     return [new(B, J, 3), new(B, J, 3, 3), new(B, V, 3) if return_vertices else new(0)]

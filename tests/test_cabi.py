@@ -129,3 +129,26 @@ def test_torch_library_operators_registered(model_root):
         assert [tuple(t.shape) for t in out] == [(5, 72), (5, 10), (5, 3), (5,), (5, 24, 3, 3), (5, 24, 3, 3), (0,)]
         fw = torch.ops.smplfitter_amd.forward(mid, torch.empty((5, 72)), None, None, None, None, None, True)
         assert [tuple(t.shape) for t in fw] == [(5, 24, 3), (5, 24, 3, 3), (5, m.num_vertices, 3)]
+
+
+def test_model_unpickler_is_restricted(tmp_path):
+    """A body-model / deftrafo pickle may only reconstruct arrays, sparse matrices and plain containers:
+    any other global (here ``os.system``) is refused instead of imported."""
+    import io
+    import pickle
+
+    import scipy.sparse as sp
+
+    from smplfitter_amd import modelio
+
+    class Evil:
+        def __reduce__(self):
+            import os
+
+            return (os.system, ('true',))
+
+    with pytest.raises(pickle.UnpicklingError):
+        modelio.restricted_load(io.BytesIO(pickle.dumps({'mtx': Evil()}, protocol=2)))
+    m = sp.random(5, 7, density=0.4, format='csc', dtype=np.float64, random_state=0)
+    back = modelio.restricted_load(io.BytesIO(pickle.dumps({'mtx': m, 'a': np.arange(4.0)}, protocol=2)))
+    assert (back['mtx'] != m).nnz == 0 and np.array_equal(back['a'], np.arange(4.0))

@@ -26,17 +26,21 @@ def _worker(rank, world, port, total, tmp):
 
     J, S = 24, 10
     rs = np.random.RandomState(0)
-    full = torch.from_numpy(rs.randn(total, 3 * J + S + 3).astype(np.float32))
+    # pose | betas | trans | kid_factor | scale_corr | orientations: the optional columns travel as well
+    layout = [('pose_rotvecs', (3 * J,)), ('shape_betas', (S,)), ('trans', (3,)), ('kid_factor', ()),
+              ('scale_corr', ()), ('orientations', (J, 3, 3))]
+    width = 3 * J + S + 3 + 1 + 1 + 9 * J
+    full = torch.from_numpy(rs.randn(total, width).astype(np.float32))
 
     def fake_fit(tv, tj, **kw):  # rows of `full` keyed by the first coordinate of the "vertices"
         idx = tv[:, 0, 0].long()
-        rows = full[idx]
-        return sd.unpack_results(rows, J, S)
+        return sd.unpack_results(full[idx], layout)
 
     tv = torch.arange(total, dtype=torch.float32).view(total, 1, 1).expand(total, 2, 3).contiguous()
     out = sd.fit_sharded(fake_fit, tv, None, J, S)
-    got = sd.pack_results(out)
-    ok = torch.equal(got, full)
+    got, got_layout = sd.pack_results(out)
+    ok = torch.equal(got, full) and got_layout == layout and out['orientations'].shape == (total, J, 3, 3) \
+        and out['kid_factor'].shape == (total,)
     lo, hi = sd.shard_range(total, rank, world)
     torch.save(dict(ok=ok, lo=lo, hi=hi), os.path.join(tmp, f'r{rank}.pt'))
     dist.barrier()

@@ -1,7 +1,9 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-python tools/dbg_pg.py 2>&1 | grep -v amdgpu.ids | cut -c1-200
-python tools/dbg_det.py 4096 2>&1 | grep -v amdgpu.ids | cut -c1-120 | head -4
-for ch in 1 2; do SMPLFIT_CHUNKS=$ch python tools/ab_fit.py smpl 4096 2>/dev/null | tail -1; done
-python tools/ab_fit.py smpl 32768 2>/dev/null | tail -1
-python tools/ab_fit.py smpl 1024 2>/dev/null | tail -1
+python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "fit_goldens or full_size or hipgraph" 2>&1 | tail -2
+for rep in 1 2; do
+SMPLFIT_LIB=$PWD/build_ab/libsmplfit_prev.so python tools/ab_fit.py smpl 4096 2>/dev/null | tail -1
+python tools/ab_fit.py smpl 4096 2>/dev/null | tail -1
+done
+SMPLFIT_CHUNKS=1 SMPLFIT_LIB=$PWD/build_ab/libsmplfit_prev.so python tools/ab_fit.py smpl 4096 2>/dev/null | tail -1
+SMPLFIT_CHUNKS=1 python tools/ab_fit.py smpl 4096 2>/dev/null | tail -1
