@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <numeric>
 
@@ -347,6 +348,9 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
       }
       i = e;
     }
+    if (std::getenv("SMPLFIT_DUMP_GROUPS"))
+      for (const auto& g : t.groups)
+        std::fprintf(stderr, "group start %d count %d part %d used %d nq %d\n", g.start, g.count, g.part, g.used, g.nq);
     t.cpackB.assign(t.segments.size() * 64 * cs, 0.f);
     for (size_t sgi = 0; sgi < t.segments.size(); ++sgi)
       for (int l = 0; l < t.segments[sgi].count; ++l)

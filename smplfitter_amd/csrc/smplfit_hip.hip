@@ -23,6 +23,8 @@
 // Everything is enqueued on the caller's stream; no host synchronisation, no allocation.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -70,6 +72,10 @@ struct DevModel {
   // batch-major vertex kernels (HostTables::groups / brec / bwd)
   int ngroups, ngroups_used;
   const int32_t* groups;  // (ngroups, kGroupRec): start, count, part, used, nq, joints[12]
+  // launch order of the vertex groups, longest first (all groups / the used ones); lpt = 0 launches them in
+  // table order with the group index fastest
+  const int32_t *gorder_all, *gorder_used;
+  int lpt;
   const float* brec;
   const float* pair_c1x;
   // per joint: the resP rows (group * kResRec + 16 + 3 * slot) holding its residual moments
@@ -253,7 +259,7 @@ void launch_lbs_bm(const DevModel& d, const Workspace& ws, int B, hipStream_t st
   const int Mp = (int)align_up((size_t)B, 128);
   const size_t lds = (size_t)kGQ * 12 * 64 * 4;
   if constexpr (KW == 4)
-    hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4>), dim3(d.ngroups_used, Mp / 64), dim3(64 * kBW), lds, st, d, ws, B, Mp);
+    hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4>), d.lpt ? dim3(Mp / 64, d.ngroups_used) : dim3(d.ngroups_used, Mp / 64), dim3(64 * kBW), lds, st, d, ws, B, Mp);
   hipLaunchKernelGGL(k_psum_combine, dim3((B + 255) / 256, d.J), dim3(256), 0, st, d, ws, B, Mp);
 }
 
@@ -603,7 +609,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
       // chunk's GEMM starts later and the chunks overlap worse (1.37 vs 1.40 M fits/s)
       launch_jd_transpose(d, ws, B, st);
       const size_t lds = (size_t)kGQ * 12 * 64 * 4;
-      hipLaunchKernelGGL((k_residual_bm<10>), dim3(d.ngroups, Mp / 64), dim3(64 * kBW), lds, st, d, ws, B, Mp);
+      hipLaunchKernelGGL((k_residual_bm<10>), d.lpt ? dim3(Mp / 64, d.ngroups) : dim3(d.ngroups, Mp / 64), dim3(64 * kBW), lds, st, d, ws, B, Mp);
       hipLaunchKernelGGL((k_pair_gram_bm<10>), dim3(kGramChunks, Mp / 64), dim3(64), 0, st, d, ws, B, Mp);
       hipLaunchKernelGGL((k_gram_combine_bm<10>), dim3((B + 255) / 256, 10 + 3 + 3 * d.J + sf::ne_ng(10)),
                          dim3(256), 0, st, d, ws, B, Mp);
@@ -883,6 +889,17 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
       if (g.used) ++d.ngroups_used;  // used parts come first in slot order
     }
     up(gr, &d.groups);
+    {
+      std::vector<int32_t> oa(t.groups.size()), ou;
+      for (size_t g = 0; g < oa.size(); ++g) oa[g] = (int32_t)g;
+      std::stable_sort(oa.begin(), oa.end(), [&](int32_t a, int32_t b) { return t.groups[a].count > t.groups[b].count; });
+      for (int32_t g : oa)
+        if (g < d.ngroups_used) ou.push_back(g);
+      up(oa, &d.gorder_all);
+      up(ou, &d.gorder_used);
+      const char* e = std::getenv("SMPLFIT_LPT");
+      d.lpt = e ? std::atoi(e) : 1;
+    }
     std::vector<int32_t> mb_start(t.J + 1, 0), mb_row;
     for (int j = 0; j < t.J; ++j) {
       for (size_t g = 0; g < t.groups.size(); ++g)
@@ -1354,8 +1371,8 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
         return 0;
       case SMPLFIT_KERNEL_SHAPE_ACCUM: {
         if (bm) {
-          hipLaunchKernelGGL((k_residual_bm<10>), dim3(d.ngroups, Mp / 64), dim3(64 * kBW),
-                             (size_t)kGQ * 12 * 64 * 4, st, d, ws, batch, Mp);
+          hipLaunchKernelGGL((k_residual_bm<10>), d.lpt ? dim3(Mp / 64, d.ngroups) : dim3(d.ngroups, Mp / 64),
+                             dim3(64 * kBW), (size_t)kGQ * 12 * 64 * 4, st, d, ws, batch, Mp);
           return 0;
         }
 #define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, batch, false, st)
