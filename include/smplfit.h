@@ -296,7 +296,10 @@ enum smplfit_kernel_id {
   SMPLFIT_KERNEL_SHAPE_SOLVE = 4,   /* K4 fp64 Cholesky solve                                      */
   SMPLFIT_KERNEL_LBS_PARTSUM = 5,   /* K5 vertices at the solution + part sums                     */
   SMPLFIT_KERNEL_PAIR_GRAM = 6,     /* batch-major path: Gramian from the rotations (k_pair_gram_bm) */
-  SMPLFIT_KERNEL_TRANSPOSE = 7,     /* batch-major path: targets to the instance-innermost layout  */
+  SMPLFIT_KERNEL_TRANSPOSE = 7,     /* batch-major path: targets to the instance-innermost, part-sorted
+                                       layout in one pass (k_layout_targets)                        */
+  SMPLFIT_KERNEL_TEMPLATE_PARTSUM = 8, /* batch-major path: part sums against the template (first
+                                       rotation estimate, k_template_partsum_bm)                    */
 };
 int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, int reps,
                             void* workspace, size_t workspace_bytes, void* hip_stream,

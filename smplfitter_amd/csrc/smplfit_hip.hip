@@ -59,6 +59,7 @@ struct DevModel {
   int V, J, S, P, Vp, Kp, KW, n_used, nseg;
   sf::JointTabs jt;
   const int32_t* perm;      // (Vp)
+  const int32_t* inv_slot;  // (V) sorted slot of every original vertex
   const int32_t* segments;  // (nseg,3)
   const int32_t* part_seg_start;  // (J+1) first segment of each part (empty range: unused part)
   const float *vt, *dm, *sd, *wval, *pdSw, *j_template, *cpackA, *cpackB, *gblob;
@@ -160,7 +161,8 @@ struct Workspace {
   float* tjs;      // (B,J,3) target joints times the scale (scale_target refinement)
   // batch-major path: streams with the instance index innermost (lane = instance reads coalesce)
   float* vpT;      // (Mp/64, 3*Vp, 64) v_posed, written by the GEMM
-  float* tT;       // (Mp/64, 3*Vp, 64) centred targets, transposed from tvs
+  float* tT;       // (Mp/64, 3*Vp, 64) targets AS GIVEN at their sorted slots (padding slots: the mean); the
+                   // consumers subtract ws.mean (k_layout_targets / k_mean_finish)
   float* psumP;    // (ngroups, 16, Mp) part sums per vertex group
   float* resP;     // (ngroups, kResRec, Mp) residual-pass sums per vertex group
   float* gramP;    // (kGramChunks, NG, Mp) pair-Gram partial sums
@@ -252,6 +254,18 @@ bool bm_applies(const DevModel& d) {
 void launch_jd_transpose(const DevModel& d, const Workspace& ws, int B, hipStream_t st) {
   const int Mp = (int)align_up((size_t)B, 128), Ns = d.J * sf::jd_stride(d.S), Np = (int)align_up((size_t)Ns, 64);
   hipLaunchKernelGGL(k_transpose_targets, dim3(Np / 64, Mp / 64), dim3(256), 0, st, ws.jd, ws.jdT, B, Np, Mp, Ns);
+}
+
+// One-pass target layout of the batch-major path (k_layout_targets, k_mean_finish, k_template_partsum_bm):
+// ws.tT, ws.mean, ws.tjc and the template part sums ws.psum.  ws.resP serves as the slab-sum scratch.
+void launch_layout_bm(const DevModel& d, const float* tv, const float* tj, const Workspace& ws, int B, hipStream_t st) {
+  const int Mp = (int)align_up((size_t)B, 128), nslab = (d.V + kSlabV - 1) / kSlabV;
+  hipLaunchKernelGGL(k_layout_targets, dim3(nslab, Mp / 64), dim3(256), (size_t)64 * kSlabRow * 4, st, d, tv, ws.tT,
+                     ws.resP, B, Mp);
+  hipLaunchKernelGGL(k_mean_finish, dim3(Mp / 64), dim3(256), 0, st, d, tj, ws.resP, ws, B, Mp, nslab);
+  hipLaunchKernelGGL(k_template_partsum_bm, d.lpt ? dim3(Mp / 64, d.ngroups_used) : dim3(d.ngroups_used, Mp / 64),
+                     dim3(64 * kBW), 0, st, d, ws, B, Mp);
+  hipLaunchKernelGGL(k_psum_combine, dim3((B + 255) / 256, d.J), dim3(256), 0, st, d, ws, B, Mp);
 }
 
 template <int S, int KW>
@@ -540,12 +554,11 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   // joints (bodyfitter.py:1018-1028)
   const bool eff_v = joints ? (vw && jw) : (vw != nullptr);
   const bool eff_j = joints && vw && jw;
-  launch_center_sort(d, tv, tj, vw, ws, B, st);
   const bool bm = bm_applies(d) && joints && !vw && !o.rotations_only && !o.scale_mode;
-  if (bm) {
-    const int Mp = (int)align_up((size_t)B, 128), N = 3 * d.Vp;
-    hipLaunchKernelGGL(k_transpose_targets, dim3(N / 64, Mp / 64), dim3(256), 0, st, ws.tvs, ws.tT, B, N, Mp, N);
-  }
+  // a warm-started fit evaluates its first part sums against the posed model with the wave-per-instance
+  // kernel, which reads the per-instance sorted copy ws.tvs: that copy is produced as well then
+  if (!bm || o.init_pose || o.init_betas) launch_center_sort(d, tv, tj, vw, ws, B, st);
+  if (bm) launch_layout_bm(d, tv, tj, ws, B, st);
   const float* tj_rot = ws.tjc;
   if (!joints) {  // regressed target joints from the centred vertices (bodyfitter.py:1342-1344)
     hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(64), 0, st, d, ws.tvs, ws.tjreg);
@@ -608,7 +621,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
       // joint rows instance-innermost for the three kernels below; AFTER the GEMM: in front of it the
       // chunk's GEMM starts later and the chunks overlap worse (1.37 vs 1.40 M fits/s)
       launch_jd_transpose(d, ws, B, st);
-      const size_t lds = (size_t)kGQ * 12 * 64 * 4;
+      const size_t lds = kResidualLds;
       hipLaunchKernelGGL((k_residual_bm<10>), d.lpt ? dim3(Mp / 64, d.ngroups) : dim3(d.ngroups, Mp / 64), dim3(64 * kBW), lds, st, d, ws, B, Mp);
       hipLaunchKernelGGL((k_pair_gram_bm<10>), dim3(kGramChunks, Mp / 64), dim3(64), 0, st, d, ws, B, Mp);
       hipLaunchKernelGGL((k_gram_combine_bm<10>), dim3((B + 255) / 256, 10 + 3 + 3 * d.J + sf::ne_ng(10)),
@@ -889,6 +902,12 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
       if (g.used) ++d.ngroups_used;  // used parts come first in slot order
     }
     up(gr, &d.groups);
+    {
+      std::vector<int32_t> inv(t.V, 0);
+      for (int i = 0; i < t.Vp; ++i)
+        if (t.perm[i] >= 0) inv[t.perm[i]] = i;
+      up(inv, &d.inv_slot);
+    }
     {
       std::vector<int32_t> oa(t.groups.size()), ou;
       for (size_t g = 0; g < oa.size(); ++g) oa[g] = (int32_t)g;
@@ -1365,14 +1384,20 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
         hipLaunchKernelGGL((k_pair_gram_bm<10>), dim3(kGramChunks, Mp / 64), dim3(64), 0, st, d, ws, batch, Mp);
         return 0;
       case SMPLFIT_KERNEL_TRANSPOSE:
-        if (!bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "transpose kernel: batch-major path not active");
-        hipLaunchKernelGGL(k_transpose_targets, dim3(3 * d.Vp / 64, Mp / 64), dim3(256), 0, st, ws.tvs, ws.tT,
-                           batch, 3 * d.Vp, Mp, 3 * d.Vp);
+        if (!bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "layout kernel: batch-major path not active");
+        // the hook has no target pointer: ws.tvs (unused on this path, >= B*V*3 floats) stands in for the rows
+        hipLaunchKernelGGL(k_layout_targets, dim3((d.V + kSlabV - 1) / kSlabV, Mp / 64), dim3(256),
+                           (size_t)64 * kSlabRow * 4, st, d, ws.tvs, ws.tT, ws.resP, batch, Mp);
+        return 0;
+      case SMPLFIT_KERNEL_TEMPLATE_PARTSUM:
+        if (!bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "template part sums: batch-major path not active");
+        hipLaunchKernelGGL(k_template_partsum_bm, d.lpt ? dim3(Mp / 64, d.ngroups_used) : dim3(d.ngroups_used, Mp / 64),
+                           dim3(64 * kBW), 0, st, d, ws, batch, Mp);
         return 0;
       case SMPLFIT_KERNEL_SHAPE_ACCUM: {
         if (bm) {
           hipLaunchKernelGGL((k_residual_bm<10>), d.lpt ? dim3(Mp / 64, d.ngroups) : dim3(d.ngroups, Mp / 64),
-                             dim3(64 * kBW), (size_t)kGQ * 12 * 64 * 4, st, d, ws, batch, Mp);
+                             dim3(64 * kBW), kResidualLds, st, d, ws, batch, Mp);
           return 0;
         }
 #define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, batch, false, st)
