@@ -49,6 +49,7 @@ SF_HD F4 ld4(const float* p) { return *reinterpret_cast<const F4*>(p); }
 struct JointTabs {
   int J, S, num_levels, adj_last_level, P, Kp;
   int n_kid;  // 1: the last of the S shape unknowns is the kid blend shape
+  int n_pad;  // zero shape directions in front of it (HostTables::n_pad): pinned to 0 by a unit ridge
   const int32_t *parents, *fk_js, *fk_level_start, *cas_start, *cas_flat, *part_type, *toe_src;
   const int32_t *adj_level_start, *adj_parts;
   const float *j_ext, *bone_ext;  // (J,3,S+1)
@@ -318,6 +319,14 @@ SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
 // and finishes with this instance's own translation.
 // Outputs: beta (S), trans (3), rjoints (J,3), jb (J,4) = T0 + T' beta (skinning translation).
 // ---------------------------------------------------------------------------------------------
+// Ridge weight of shape unknown i (bodyfitter.py:1064-1071; kid unknown :1235-1242); padding unknowns: 1.
+SF_HD double ridge_weight(const JointTabs& tb, int i, float beta_reg, float beta_reg2, float kid_reg) {
+  const int S = tb.S;
+  if (i >= S - tb.n_kid) return (double)kid_reg;
+  if (i >= S - tb.n_kid - tb.n_pad) return 1.0;
+  return (double)(i < 2 ? beta_reg2 : beta_reg);
+}
+
 template <class Ctx>
 SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const double* gramv,
                        const float* gramj, const float* pext, const float* jd, const float* mb,
@@ -354,14 +363,14 @@ SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const doubl
       double g = sum[ne_g(S, j, i)];
       g -= (SA[i] * SA[j] + SA[S + i] * SA[S + j] + SA[2 * S + i] * SA[2 * S + j]) / W;
       if (i == j)  // (:1064-1071; kid unknown :1235-1242)
-        g += (double)(i >= S - tb.n_kid ? kid_reg : (i < 2 ? beta_reg2 : beta_reg));
+        g += ridge_weight(tb, i, beta_reg, beta_reg2, kid_reg);
       M[i * S + j] = g;
     }
   }
   SF_FOR(i, S) {
     double r = sum[NG + i] - (SA[i] * Sb[0] + SA[S + i] * Sb[1] + SA[2 * S + i] * Sb[2]) / W;
     if (reg_ref)  // ridge towards reference values: + lambda_i ref_i (:1072-1081, :1224-1255)
-      r += (double)(i >= S - tb.n_kid ? kid_reg : (i < 2 ? beta_reg2 : beta_reg)) * (double)reg_ref[i];
+      r += ridge_weight(tb, i, beta_reg, beta_reg2, kid_reg) * (double)reg_ref[i];
     x[i] = r;
   }
   cx.sync();
@@ -513,7 +522,7 @@ SF_HD void scaled_solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, cons
   double Sc[3];
   for (int c = 0; c < 3; ++c) Sc[c] = mode == 1 ? -ex[3 + c] : ex[3 + c] - Sb[c];
   auto lam = [&](int i) -> double {
-    return i == S ? (double)scale_reg : (double)(i >= S - tb.n_kid ? kid_reg : (i < 2 ? beta_reg2 : beta_reg));
+    return i == S ? (double)scale_reg : ridge_weight(tb, i, beta_reg, beta_reg2, kid_reg);
   };
   auto gcol = [&](int i) -> double { return mode == 1 ? -u[i] : u[i] - sum[NG + i]; };  // g[i]
   SF_FOR(idx, N * N) {
@@ -714,7 +723,7 @@ SF_HD void refine_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, co
     if (rel_out)
       for (int k = 0; k < 9; ++k) rel_out[j * 9 + k] = rel[k];
   }
-  if (beta_out) SF_FOR(i, S - tb.n_kid) beta_out[i] = beta[i];
+  if (beta_out) SF_FOR(i, S - tb.n_kid - tb.n_pad) beta_out[i] = beta[i];
   if (tb.n_kid && kid_out && cx.lane == 0) kid_out[0] = beta[S - 1];
   SF_FOR(c, 3) trans_out[c] = trans[c] + mean[c];  // (:519)
 }

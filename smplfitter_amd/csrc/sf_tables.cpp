@@ -23,15 +23,24 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
   const int n_kid = d.enable_kid ? 1 : 0;
   if (n_kid && (!d.kid_shapedir || !d.kid_J_shapedir))
     return "smplfit_create: enable_kid without kid_shapedir / kid_J_shapedir";
-  const int S = d.num_betas + n_kid;  // the kid blend shape is one more shape direction
+  // The kernels are instantiated for 10 and 16 betas (+ the kid unknown): any other count is padded up with zero
+  // shape directions, which the solve pins to zero with a unit ridge (sf::solve_stage); the caller sees its own
+  // num_betas everywhere (reference: BodyModel(num_betas=...) accepts any count, bodymodel.py:60-76).
+  const int nb = d.num_betas, nb_pad = nb <= 10 ? 10 : 16;
+  if (nb > 16) {
+    *unsupported = true;
+    return "smplfit_create: more than 16 betas is not supported";
+  }
+  const int n_pad = nb_pad - nb;
+  const int S = nb_pad + n_kid;  // the kid blend shape is one more shape direction (the last)
   // shape directions with the kid column appended (bodyfitter.py:52-58, :1139-1149)
-  std::vector<float> shapedirs_ext((size_t)V * 3 * S), jshapedirs_ext((size_t)J * 3 * S);
+  std::vector<float> shapedirs_ext((size_t)V * 3 * S, 0.f), jshapedirs_ext((size_t)J * 3 * S, 0.f);
   for (size_t r = 0; r < (size_t)V * 3; ++r) {
-    for (int s2 = 0; s2 < d.num_betas; ++s2) shapedirs_ext[r * S + s2] = d.shapedirs[r * d.num_betas + s2];
+    for (int s2 = 0; s2 < nb; ++s2) shapedirs_ext[r * S + s2] = d.shapedirs[r * nb + s2];
     if (n_kid) shapedirs_ext[r * S + S - 1] = d.kid_shapedir[r];
   }
   for (size_t r = 0; r < (size_t)J * 3; ++r) {
-    for (int s2 = 0; s2 < d.num_betas; ++s2) jshapedirs_ext[r * S + s2] = d.J_shapedirs[r * d.num_betas + s2];
+    for (int s2 = 0; s2 < nb; ++s2) jshapedirs_ext[r * S + s2] = d.J_shapedirs[r * nb + s2];
     if (n_kid) jshapedirs_ext[r * S + S - 1] = d.kid_J_shapedir[r];
   }
   const float* const shapedirs = shapedirs_ext.data();
@@ -40,12 +49,13 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
     *unsupported = true;
     return "smplfit_create: more than 64 joints is not supported";
   }
-  if (S < 2) {
+  if (nb < 2) {
     *unsupported = true;
     return "smplfit_create: num_betas < 2 is not supported";
   }
   t.V = V; t.J = J; t.S = S; t.P = 9 * (J - 1);
   t.n_kid = n_kid;
+  t.n_pad = n_pad;
   t.Vp = round_up(V, kVertexPad);
   // The batch-major vertex kernels need one all-zero padding slot (their out-of-range steps run on it).
   // A vertex count that is a multiple of the padding (vertex subsets of 1024, 2048, ...) gets one more

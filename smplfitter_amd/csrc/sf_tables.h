@@ -40,6 +40,9 @@ struct VertexGroup {
 struct HostTables {
   int V = 0, J = 0, S = 0, P = 0;  // S counts every shape unknown: betas + kid
   int n_kid = 0;                   // 1 if the last unknown is the kid blend shape
+  int n_pad = 0;                   // zero shape directions between the betas and the kid unknown: the kernels
+                                   // are built for 10 / 16 betas, a model with fewer is padded up (unit ridge)
+  int num_betas() const { return S - n_kid - n_pad; }  // the caller's betas
   int Vp = 0, Kp = 0, KW = 4;
   bool smpl_family = false;
   bool has_regressor = false;

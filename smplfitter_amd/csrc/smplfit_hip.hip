@@ -363,7 +363,7 @@ void launch_center_sort(const DevModel& d, const float* tv, const float* tj, con
     else if ((d).S == 11 && (d).KW == 8) { CALL(11, 8); }                      \
     else if ((d).S == 17 && (d).KW == 4) { CALL(17, 4); }                      \
     else return fail(SMPLFIT_ERR_UNSUPPORTED,                                  \
-                     "num_betas must be 10 or 16 (+1 with the kid blend shape)"); \
+                     "unsupported (shape unknowns, skinning width) combination"); \
   } while (0)
 
 size_t chunked_workspace_bytes(const sf::HostTables& t, int batch);
@@ -580,7 +580,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   const int use_ref = (o.init_betas || o.init_kid) ? 1 : 0;
   if (warm || use_ref)
     hipLaunchKernelGGL(k_fill_shape, dim3((B + 255) / 256), dim3(256), 0, st, ws, B, d.S, d.jt.n_kid,
-                       o.init_betas, std::min(o.init_nb, d.S - d.jt.n_kid), o.init_kid);
+                       o.init_betas, std::min(o.init_nb, d.S - d.jt.n_kid - d.jt.n_pad), o.init_kid);
   if (warm) {
     ForwardArgs fa{};
     fa.pose = o.init_pose;
@@ -710,7 +710,7 @@ int run_fit_known_shape(const smplfit_handle* h, const float* betas, int nb, con
     tj_rot = ws.tjreg;
   }
   hipLaunchKernelGGL(k_fill_shape, dim3((B + 255) / 256), dim3(256), 0, st, ws, B, d.S, d.jt.n_kid, betas,
-                     std::min(nb, d.S - d.jt.n_kid), kid);
+                     std::min(nb, d.S - d.jt.n_kid - d.jt.n_pad), kid);
   ForwardArgs fa{};
   fa.pose = init_pose;  // null -> rest pose
   fa.betas = ws.beta;   // (B,S) incl. the kid column: j_ext's last column is kid_J_shapedir
@@ -935,6 +935,7 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
   jt.J = t.J; jt.S = t.S; jt.num_levels = t.num_levels(); jt.adj_last_level = t.adj_last_level;
   jt.P = t.P; jt.Kp = t.Kp;
   jt.n_kid = t.n_kid;
+  jt.n_pad = t.n_pad;
   up(t.parents, &jt.parents);
   up(t.fk_js, &jt.fk_js);
   up(t.fk_level_start, &jt.fk_level_start);
@@ -997,7 +998,7 @@ int smplfit_get_info(const smplfit_handle* h, smplfit_info* info) {
   const sf::HostTables& t = h->t;
   info->num_vertices = t.V;
   info->num_joints = t.J;
-  info->num_betas = t.S - t.n_kid;
+  info->num_betas = t.num_betas();
   info->has_kid = t.n_kid;
   info->padded_vertices = t.Vp;
   info->num_used_vertices = t.n_used;
@@ -1131,7 +1132,7 @@ int smplfit_fit_ex_f32(const smplfit_handle* h, const smplfit_fit_args* args) {
   int sizes[kMaxChunks];
   // share_beta couples all instances in every shape solve: one chunk
   const int nchunk = (h->have_streams && !o.share_beta) ? chunk_plan(batch, sizes) : 1;
-  const int J = h->t.J, V = h->t.V, Sb = h->t.S - h->t.n_kid;
+  const int J = h->t.J, V = h->t.V, Sb = h->t.num_betas();
   auto run_chunk = [&](int b0, int nb, char* wsbase, hipStream_t cs) -> int {
     Workspace ws;
     carve(h->t, nb, wsbase, &ws);
@@ -1200,7 +1201,7 @@ int smplfit_fit_known_shape_f32(const smplfit_handle* h, const float* shape_beta
   const sf::HostTables& t = h->t;
   if (kid_factor && !t.n_kid)
     return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_known_shape_f32: kid_factor given to a handle without kid");
-  if (num_betas_given < 0 || num_betas_given > t.S - t.n_kid)
+  if (num_betas_given < 0 || num_betas_given > t.num_betas())
     return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_known_shape_f32: more betas than the model holds; slice first");
   KnownShapeOptions o{num_iter, final_adjust_rots ? 1 : 0, scale_fit ? 1 : 0};
   hipStream_t st = (hipStream_t)hip_stream;
@@ -1244,11 +1245,11 @@ int smplfit_forward_f32(const smplfit_handle* h, const float* pose_rotvecs,
   fa.pose = pose_rotvecs;
   fa.glob = glob_rotmats;
   fa.betas = shape_betas;
-  fa.nb = shape_betas ? std::min(num_betas_given, d.S - d.jt.n_kid) : 0;
+  fa.nb = shape_betas ? std::min(num_betas_given, d.S - d.jt.n_kid - d.jt.n_pad) : 0;
   if (kid_factor && !d.jt.n_kid)
     return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_forward_f32: kid_factor given to a handle without kid");
   fa.kid = kid_factor;
-  if (shape_betas && num_betas_given > d.S - d.jt.n_kid)
+  if (shape_betas && num_betas_given > d.S - d.jt.n_kid - d.jt.n_pad)
     return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_forward_f32: more betas than the model holds; slice first");
   fa.trans = trans;
   fa.joints = joints;
@@ -1319,7 +1320,7 @@ int smplfit_shape_solve_ex_f32(const smplfit_handle* h, const smplfit_shape_solv
   if (use_ref)  // the ridge pulls towards these (pt/bodyfitter.py:1224-1255); missing columns are 0
     hipLaunchKernelGGL(k_fill_shape, dim3((batch + 255) / 256), dim3(256), 0, st, ws, batch, d.S, d.jt.n_kid,
                        args->beta_regularizer_reference,
-                       args->beta_regularizer_reference ? std::min(args->num_reference_betas, d.S - d.jt.n_kid) : 0,
+                       args->beta_regularizer_reference ? std::min(args->num_reference_betas, d.S - d.jt.n_kid - d.jt.n_pad) : 0,
                        args->kid_regularizer_reference);
   launch_center_sort(d, args->target_vertices, args->target_joints, vertex_weights, ws, batch, st);
   JointStageArgs ja{};
@@ -1344,7 +1345,7 @@ int smplfit_shape_solve_ex_f32(const smplfit_handle* h, const smplfit_shape_solv
   if (rc) return rc;
   // a scaled solve leaves the shape as the reference returns it (undivided, :1277-1283) in beta_out
   hipLaunchKernelGGL(k_emit_solution, dim3((batch + 255) / 256), dim3(256), 0, st, ws,
-                     o.scale_mode ? ws.beta_out : ws.beta, batch, d.S, d.jt.n_kid, args->add_mean,
+                     o.scale_mode ? ws.beta_out : ws.beta, batch, d.S, d.jt.n_kid, d.S - d.jt.n_kid - d.jt.n_pad, args->add_mean,
                      args->shape_betas, args->trans, args->kid_factor);
   if (o.scale_mode)
     hipLaunchKernelGGL(k_copy, dim3(16), dim3(256), 0, st, ws.scale, args->scale_corr, (size_t)batch);

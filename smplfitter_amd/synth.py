@@ -130,6 +130,8 @@ def make_model_arrays(kind='smpl', seed=0, num_vertices=None, num_betas=10, shuf
     bone parts' twist about the bone axis is recovered from the vertices' off-axis spread
     (pt/bodyfitter.py:1398-1410), so thin parts make pose_rotvecs ill-conditioned in the reference itself;
     on the fat variant a tight pose_rotvecs comparison is meaningful."""
+    if kind.endswith('_b16'):  # the same construction with 16 shape directions ('smpl_b16')
+        kind, num_betas = kind[:-4], 16
     fat = kind.endswith('_fat')
     kind = kind[:-4] if fat else kind
     rs = np.random.RandomState(seed)
@@ -236,9 +238,9 @@ def write_model_files(root, kind='smpl', seed=0, num_vertices=None):
     File names follow the reference loader (src/smplfitter/common.py:266-283)."""
     arrs = make_model_arrays(kind, seed, num_vertices)
     kid = arrs.pop('kid_template')
-    d = osp.join(root, kind)  # 'smplx_fat' lives in its own directory, same official file name
+    d = osp.join(root, kind)  # 'smplx_fat' / 'smpl_b16' live in their own directory, same official file name
     os.makedirs(d, exist_ok=True)
-    if kind == 'smpl':
+    if not kind.startswith('smplx'):
         path = osp.join(d, 'basicmodel_neutral_lbs_10_207_0_v1.1.0.pkl')
         tmp = path + f'.tmp{os.getpid()}'
         with open(tmp, 'wb') as f:
@@ -264,7 +266,7 @@ def ensure_model_root(root=None, kinds=('smpl',), seed=0):
         root = os.getenv('SMPLFIT_SYNTH_ROOT', f'/tmp/smplfit_synth_models_seed{seed}')
     for kind in kinds:
         fn = (
-            'basicmodel_neutral_lbs_10_207_0_v1.1.0.pkl' if kind == 'smpl' else 'SMPLX_NEUTRAL.npz'
+            'SMPLX_NEUTRAL.npz' if kind.startswith('smplx') else 'basicmodel_neutral_lbs_10_207_0_v1.1.0.pkl'
         )
         if not (
             osp.exists(osp.join(root, kind, fn))

@@ -27,6 +27,7 @@ sf::JointTabs make_tabs(const sf::HostTables& t) {
   jt.J = t.J; jt.S = t.S; jt.num_levels = t.num_levels(); jt.adj_last_level = t.adj_last_level;
   jt.P = t.P; jt.Kp = t.Kp;
   jt.n_kid = t.n_kid;
+  jt.n_pad = t.n_pad;
   jt.parents = t.parents.data(); jt.fk_js = t.fk_js.data();
   jt.fk_level_start = t.fk_level_start.data(); jt.cas_start = t.cas_start.data();
   jt.cas_flat = t.cas_flat.data(); jt.part_type = t.part_type.data(); jt.toe_src = t.toe_src.data();
@@ -335,7 +336,7 @@ int fit_impl(const sf::HostTables& t, const float* tv, const float* tj, const fl
   }
   const bool warm = w.pose || w.betas;
   if (warm || w.kid) {  // k_fill_shape: the ridge reference also for an initial_kid_factor on its own
-    const int nbe = std::min(w.nb, S - t.n_kid);
+    const int nbe = std::min(w.nb, t.num_betas());
     for (int b = 0; b < B; ++b) {
       for (int s = 0; s < S - t.n_kid; ++s)
         e.beta[(size_t)b * S + s] = (w.betas && s < nbe) ? w.betas[(size_t)b * w.nb + s] : 0.f;
@@ -466,7 +467,7 @@ int fit_impl(const sf::HostTables& t, const float* tv, const float* tj, const fl
                      e.rjoints.data() + (size_t)b * t.J * 3, jw ? jw + (size_t)b * t.J : nullptr,
                      e.G.data() + (size_t)b * t.J * 9, e.beta.data() + (size_t)b * S,
                      e.trans.data() + (size_t)b * 3, e.mean.data() + (size_t)b * 3, final_adjust != 0,
-                     pose + (size_t)b * t.J * 3, betas + (size_t)b * (S - t.n_kid), trans + (size_t)b * 3,
+                     pose + (size_t)b * t.J * 3, betas + (size_t)b * t.num_betas(), trans + (size_t)b * 3,
                      kid ? kid + b : nullptr, orient ? orient + (size_t)b * t.J * 9 : nullptr, nullptr,
                      w.scale_mode == 2 ? scale.data() + b : nullptr);
   return 0;
@@ -487,7 +488,7 @@ int known_shape_impl(const sf::HostTables& t, const float* betas, int nb, const 
     e.regress(e.tvs.data(), false, e.tjreg.data(), B);
     tj_rot = e.tjreg.data();
   }
-  const int nbe = std::min(nb, S - t.n_kid);
+  const int nbe = std::min(nb, t.num_betas());
   for (int b = 0; b < B; ++b) {
     for (int s = 0; s < S - t.n_kid; ++s) e.beta[(size_t)b * S + s] = s < nbe ? betas[(size_t)b * nb + s] : 0.f;
     if (t.n_kid) e.beta[(size_t)b * S + S - 1] = kid ? kid[b] : 0.f;
@@ -598,6 +599,8 @@ int hostemu_fit(const smplfit_model_desc* d, const float* tv, const float* tj, c
     return fit_impl<16, 4>(t, tv, tj, vw, jw, B, num_iter, reg, reg2, kid_reg, final_adjust, pose, betas, trans, kid, orient, G0_out);
   if (t.S == 11 && t.KW == 4)
     return fit_impl<11, 4>(t, tv, tj, vw, jw, B, num_iter, reg, reg2, kid_reg, final_adjust, pose, betas, trans, kid, orient, G0_out);
+  if (t.S == 17 && t.KW == 4)
+    return fit_impl<17, 4>(t, tv, tj, vw, jw, B, num_iter, reg, reg2, kid_reg, final_adjust, pose, betas, trans, kid, orient, G0_out);
   g_err = "hostemu: unsupported (S, KW)";
   return -2;
 }
@@ -642,7 +645,7 @@ int hostemu_fit_known_shape(const smplfit_model_desc* d, const float* betas, int
 #define HE_KS(S_, KW_) \
   if (t.S == S_ && t.KW == KW_) \
     return known_shape_impl<S_, KW_>(t, betas, nb, kid, init_pose, tv, tj, vw, jw, B, num_iter, final_adjust, scale_fit, pose, trans, scale_out, orient)
-  HE_KS(10, 4); HE_KS(10, 8); HE_KS(16, 4); HE_KS(11, 4);
+  HE_KS(10, 4); HE_KS(10, 8); HE_KS(16, 4); HE_KS(11, 4); HE_KS(17, 4);
 #undef HE_KS
   g_err = "hostemu: unsupported (S, KW)";
   return -2;
@@ -659,6 +662,7 @@ int hostemu_forward(const smplfit_model_desc* d, const float* pose, const float*
   if (t.S == 10 && t.KW == 8) return forward_impl<10, 8>(t, pose, glob, betas, nb, trans, kid, B, verts, joints, orient);
   if (t.S == 16 && t.KW == 4) return forward_impl<16, 4>(t, pose, glob, betas, nb, trans, kid, B, verts, joints, orient);
   if (t.S == 11 && t.KW == 4) return forward_impl<11, 4>(t, pose, glob, betas, nb, trans, kid, B, verts, joints, orient);
+  if (t.S == 17 && t.KW == 4) return forward_impl<17, 4>(t, pose, glob, betas, nb, trans, kid, B, verts, joints, orient);
   g_err = "hostemu: unsupported (S, KW)";
   return -2;
 }

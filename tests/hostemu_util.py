@@ -23,16 +23,23 @@ def load():
     if _cache is not None:
         return _cache
     deps = [SRC] + [osp.join(CSRC, f) for f in ('sf_math.h', 'sf_stages.h', 'sf_tables.h', 'sf_tables.cpp')]
-    if not osp.exists(SO) or any(osp.getmtime(d) > osp.getmtime(SO) for d in deps):
+    # HOSTEMU_SANITIZE=1: the same sources (the product's table builder and stage code) under
+    # AddressSanitizer + UBSan; run as  LD_PRELOAD=$(gcc -print-file-name=libasan.so) HOSTEMU_SANITIZE=1
+    # ASAN_OPTIONS=detect_leaks=0 python -m pytest tests/test_hostemu.py   (tools/asan_hostemu.sh)
+    san = os.getenv('HOSTEMU_SANITIZE') == '1'
+    so = SO.replace('.so', '_asan.so') if san else SO
+    if not osp.exists(so) or any(osp.getmtime(d) > osp.getmtime(so) for d in deps):
         os.makedirs(BUILD, exist_ok=True)
-        tmp = SO + f'.tmp{os.getpid()}'
+        tmp = so + f'.tmp{os.getpid()}'
+        flags = ['-O1', '-g', '-fsanitize=address,undefined', '-fno-omit-frame-pointer',
+                 '-fno-sanitize-recover=undefined'] if san else ['-O2']
         subprocess.run(
-            ['g++', '-O2', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', SRC,
+            ['g++', *flags, '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off', SRC,
              osp.join(CSRC, 'sf_tables.cpp'), '-o', tmp],
             check=True,
         )
-        os.replace(tmp, SO)
-    lib = C.CDLL(SO)
+        os.replace(tmp, so)
+    lib = C.CDLL(so)
     vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
     lib.hostemu_fit.argtypes = [C.POINTER(_lib.ModelDesc), vp, vp, vp, vp, i32, i32, f32, f32, f32, i32, vp, vp, vp, vp, vp, vp]
     lib.hostemu_fit.restype = i32

@@ -730,3 +730,30 @@ def test_cabi_error_paths(model_root, golden, dev):
             h.ptr, out['b'].data_ptr(), 10, out['s'].data_ptr(), None, tv.data_ptr(), None, None, None, B, 1,
             1, 0, out['p'].data_ptr(), out['t'].data_ptr(), None, None, None, ws.data_ptr(), ws.numel(), None))
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('nb', [6, 13])
+def test_num_betas_padding(nb, model_root, golden, dev):
+    """BodyModel(num_betas=6 / 13): the library pads the shape unknowns to the 10 / 16 its kernels are built
+    for and pins the padding to zero; shapes and results are the caller's count (reference fixture
+    golden_nb_smpl.npz, tests/golden/make_golden_nb.py)."""
+    from smplfitter_amd import modelio
+    from smplfitter_amd.pt import BodyFitter, BodyModel
+
+    gnb = golden('nb_smpl')
+    root = f'{model_root}/{util.NB_DIR[nb]}'
+    md = modelio.load_model('smpl', 'neutral', model_root=root, num_betas=nb)
+    om64, _ = util.make_oracle(md, 'smpl', np.float64)
+    m = BodyModel('smpl', 'neutral', model_root=root, num_betas=nb, device=dev)
+    assert m.num_betas == nb
+    fw = to_np(m(t(gnb[f'nb{nb}.pose'], dev), t(gnb[f'nb{nb}.betas'], dev), t(gnb[f'nb{nb}.trans'], dev)))
+    assert np.abs(fw['vertices'][:, ::50] - gnb[f'nb{nb}.fwd_vertices_every_50th']).max() < 2e-6
+    assert np.abs(fw['joints'] - gnb[f'nb{nb}.fwd_joints']).max() < 2e-6
+    tv, tj = t(gnb[f'nb{nb}.target_vertices'], dev), t(gnb[f'nb{nb}.target_joints'], dev)
+    for nb2, kid, cfg in util.NB_CASES:
+        if nb2 != nb:
+            continue
+        f = BodyFitter(m, enable_kid=kid)
+        keys = ['pose_rotvecs', 'shape_betas', 'trans'] + (['kid_factor'] if kid else [])
+        o = to_np(f.fit(tv, tj, requested_keys=keys, **util.NB_CFG[cfg]))
+        util.check_nb(om64, gnb, nb, kid, cfg, o)

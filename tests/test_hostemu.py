@@ -188,3 +188,22 @@ def test_share_scale_goldens(name, model_root, golden):
         util.check_share_scale(om, name, case, o, gk, kid_fit)
         n += 1
     assert n >= 1
+
+
+@pytest.mark.parametrize('nb', [6, 13])
+def test_num_betas_padding(nb, model_root, golden):
+    """num_betas = 6 / 13: the tables pad the shape unknowns to 10 / 16 and pin the padding with a unit
+    ridge; the caller sees its own count (reference fixture golden_nb_smpl.npz)."""
+    from smplfitter_amd import modelio
+
+    gnb = golden('nb_smpl')
+    md = modelio.load_model('smpl', 'neutral', model_root=f'{model_root}/{util.NB_DIR[nb]}', num_betas=nb)
+    om64, _ = util.make_oracle(md, 'smpl', np.float64)
+    fw = H.forward(md, 'smpl', gnb[f'nb{nb}.pose'], gnb[f'nb{nb}.betas'], gnb[f'nb{nb}.trans'])
+    assert np.abs(fw['vertices'][:, ::50] - gnb[f'nb{nb}.fwd_vertices_every_50th']).max() < 2e-6
+    assert np.abs(fw['joints'] - gnb[f'nb{nb}.fwd_joints']).max() < 2e-6
+    for nb2, kid, cfg in util.NB_CASES:
+        if nb2 != nb:
+            continue
+        o = H.fit(md, 'smpl', gnb[f'nb{nb}.target_vertices'], gnb[f'nb{nb}.target_joints'], enable_kid=kid, **util.NB_CFG[cfg])
+        util.check_nb(om64, gnb, nb, kid, cfg, o)

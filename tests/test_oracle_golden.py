@@ -279,3 +279,22 @@ def test_share_scale_goldens(name, model_root, golden):
         util.check_share_scale(om, name, case, o, gk, kid_fit)
         n += 1
     assert n >= 1
+
+
+@pytest.mark.parametrize('nb', [6, 13])
+def test_num_betas_goldens(nb, model_root, golden):
+    """The oracle against the reference's fixture for num_betas = 6 / 13 (golden_nb_smpl.npz)."""
+    from smplfitter_amd import modelio
+
+    gnb = golden('nb_smpl')
+    md = modelio.load_model('smpl', 'neutral', model_root=f'{model_root}/{util.NB_DIR[nb]}', num_betas=nb)
+    om64, _ = util.make_oracle(md, 'smpl', np.float64)
+    om, _ = util.make_oracle(md, 'smpl', np.float32)
+    fw = om.forward(gnb[f'nb{nb}.pose'], gnb[f'nb{nb}.betas'], gnb[f'nb{nb}.trans'])
+    assert np.abs(fw['vertices'][:, ::50] - gnb[f'nb{nb}.fwd_vertices_every_50th']).max() < 2e-6
+    for nb2, kid, cfg in util.NB_CASES:
+        if nb2 != nb:
+            continue
+        of = util.O.OracleFitter(om, enable_kid=kid)
+        o = of.fit(gnb[f'nb{nb}.target_vertices'], gnb[f'nb{nb}.target_joints'], **util.NB_CFG[cfg])
+        util.check_nb(om64, gnb, nb, kid, cfg, o)

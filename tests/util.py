@@ -22,6 +22,27 @@ def load_md(root, name, g=None):
     return kind, modelio.load_model(kind, 'neutral', model_root=f'{root}/{model_dir(name)}', num_betas=10, **kw)
 
 
+# num_betas outside the counts the kernels are instantiated for (tests/golden/make_golden_nb.py)
+NB_DIR = {6: 'smpl', 13: 'smpl_b16'}  # model directory under the synthetic root
+NB_CASES = [(nb, kid, cfg) for nb in (6, 13) for kid in (False, True) for cfg in ('it3_reg1', 'it2_reg0')]
+NB_CFG = dict(it3_reg1=dict(num_iter=3, beta_regularizer=1.0),
+              it2_reg0=dict(num_iter=2, beta_regularizer=0.0, final_adjust_rots=False))
+
+
+def check_nb(om64, gnb, nb, kid, cfg, o):
+    """Assertions of a fit with ``nb`` betas against the reference's fixture: mesh gate 1e-4 m."""
+    pre = f'nb{nb}.kid{int(kid)}.{cfg}.'
+    ref = {k: gnb[pre + k] for k in ('pose_rotvecs', 'shape_betas', 'trans') + (('kid_factor',) if kid else ())}
+    assert o['shape_betas'].shape == ref['shape_betas'].shape == (ref['trans'].shape[0], nb)
+    kw_o = dict(kid_factor=o['kid_factor']) if kid else {}
+    kw_r = dict(kid_factor=ref['kid_factor']) if kid else {}
+    va = om64.forward(o['pose_rotvecs'], o['shape_betas'], o['trans'], **kw_o)['vertices']
+    vb = om64.forward(ref['pose_rotvecs'], ref['shape_betas'], ref['trans'], **kw_r)['vertices']
+    assert np.linalg.norm(va - vb, axis=-1).max() < 1e-4, (nb, kid, cfg)
+    assert np.abs(o['trans'] - ref['trans']).max() < 2e-5, (nb, kid, cfg)
+    assert np.abs(o['shape_betas'] - ref['shape_betas']).max() < 2e-3, (nb, kid, cfg)
+
+
 def model_dir(name):
     """Directory of golden set ``name`` under the synthetic model root (smplxfat: the fat-part SMPL-X
     variant of synth.make_model_arrays('smplx_fat'), its own directory, the official SMPL-X file name)."""
