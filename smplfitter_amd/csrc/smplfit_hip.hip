@@ -247,7 +247,9 @@ bool use_bm() {
 bool bm_applies(const DevModel& d) {
   // Vp > V: the batch-major loops run their out-of-range steps on the first padding slot
   // (below ~1000 vertices the staging of a workgroup's joints outweighs its vertex work)
-  return use_bm() && d.KW == 4 && d.S == 10 && d.ngroups > 0 && d.V >= 1024 && d.Vp > d.V;
+  // (S = 11 is instantiated and parity-tested, SMPLFIT_BM_KID=1, but its pair-Gram kernel spills: off by default)
+  static const bool kid_bm = [] { const char* e = getenv("SMPLFIT_BM_KID"); return e && e[0] == '1'; }();
+  return use_bm() && d.KW == 4 && (d.S == 10 || (kid_bm && d.S == 11)) && d.ngroups > 0 && d.V >= 1024 && d.Vp > d.V;
 }
 
 // joint rows of the current rotations, instance-innermost, for k_pair_gram_bm
@@ -268,12 +270,40 @@ void launch_layout_bm(const DevModel& d, const float* tv, const float* tj, const
   hipLaunchKernelGGL(k_psum_combine, dim3((B + 255) / 256, d.J), dim3(256), 0, st, d, ws, B, Mp);
 }
 
+// K3' + K3g + K3c of the batch-major path for 10 betas (S = 10) and 10 betas + the kid unknown (S = 11)
+template <int S>
+void launch_residual_bm_s(const DevModel& d, const Workspace& ws, int B, hipStream_t st, int which = 7) {
+  const int Mp = (int)align_up((size_t)B, 128);
+  if (which & 1)
+    hipLaunchKernelGGL((k_residual_bm<S>), d.lpt ? dim3(Mp / 64, d.ngroups) : dim3(d.ngroups, Mp / 64),
+                       dim3(64 * kBW), kResidualLds, st, d, ws, B, Mp);
+  if (which & 2)
+    hipLaunchKernelGGL((k_pair_gram_bm<S>), dim3(kGramChunks, Mp / 64), dim3(64), 0, st, d, ws, B, Mp);
+  if (which & 4)
+    hipLaunchKernelGGL((k_gram_combine_bm<S>), dim3((B + 255) / 256, S + 3 + 3 * d.J + sf::ne_ng(S)), dim3(256), 0,
+                       st, d, ws, B, Mp);
+}
+void launch_residual_bm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, int which = 7) {
+  if (d.S == 11) launch_residual_bm_s<11>(d, ws, B, st, which);
+  else launch_residual_bm_s<10>(d, ws, B, st, which);
+}
+
+// write_v (joints-omitted fits): all groups, the vertices at the solution written over ws.vpT, then the reference
+// joints of the next rotation pass regressed from them into ws.rjreg
 template <int S, int KW>
-void launch_lbs_bm(const DevModel& d, const Workspace& ws, int B, hipStream_t st) {
+void launch_lbs_bm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, bool write_v = false) {
   const int Mp = (int)align_up((size_t)B, 128);
   const size_t lds = (size_t)kGQ * 12 * 64 * 4;
-  if constexpr (KW == 4)
-    hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4>), d.lpt ? dim3(Mp / 64, d.ngroups_used) : dim3(d.ngroups_used, Mp / 64), dim3(64 * kBW), lds, st, d, ws, B, Mp);
+  if constexpr (KW == 4) {
+    if (write_v) {
+      hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4, true>), d.lpt ? dim3(Mp / 64, d.ngroups) : dim3(d.ngroups, Mp / 64),
+                         dim3(64 * kBW), lds, st, d, ws, B, Mp);
+      hipLaunchKernelGGL(k_regress_joints_bm<false>, dim3(Mp / 64, d.J), dim3(64), 0, st, d, ws.vpT, nullptr, ws.rjreg, B);
+    } else {
+      hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4>), d.lpt ? dim3(Mp / 64, d.ngroups_used) : dim3(d.ngroups_used, Mp / 64),
+                         dim3(64 * kBW), lds, st, d, ws, B, Mp);
+    }
+  }
   hipLaunchKernelGGL(k_psum_combine, dim3((B + 255) / 256, d.J), dim3(256), 0, st, d, ws, B, Mp);
 }
 
@@ -554,14 +584,18 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   // joints (bodyfitter.py:1018-1028)
   const bool eff_v = joints ? (vw && jw) : (vw != nullptr);
   const bool eff_j = joints && vw && jw;
-  const bool bm = bm_applies(d) && joints && !vw && !o.rotations_only && !o.scale_mode;
+  const bool bm = bm_applies(d) && !vw && !o.rotations_only && !o.scale_mode;
   // a warm-started fit evaluates its first part sums against the posed model with the wave-per-instance
   // kernel, which reads the per-instance sorted copy ws.tvs: that copy is produced as well then
   if (!bm || o.init_pose || o.init_betas) launch_center_sort(d, tv, tj, vw, ws, B, st);
   if (bm) launch_layout_bm(d, tv, tj, ws, B, st);
   const float* tj_rot = ws.tjc;
   if (!joints) {  // regressed target joints from the centred vertices (bodyfitter.py:1342-1344)
-    hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(64), 0, st, d, ws.tvs, ws.tjreg);
+    if (bm)
+      hipLaunchKernelGGL(k_regress_joints_bm<true>, dim3((int)align_up((size_t)B, 128) / 64, d.J), dim3(64), 0, st, d,
+                         ws.tT, ws.mean, ws.tjreg, B);
+    else
+      hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(64), 0, st, d, ws.tvs, ws.tjreg);
     tj_rot = ws.tjreg;
   }
   JointStageArgs ja{};
@@ -622,10 +656,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
       // chunk's GEMM starts later and the chunks overlap worse (1.37 vs 1.40 M fits/s)
       launch_jd_transpose(d, ws, B, st);
       const size_t lds = kResidualLds;
-      hipLaunchKernelGGL((k_residual_bm<10>), d.lpt ? dim3(Mp / 64, d.ngroups) : dim3(d.ngroups, Mp / 64), dim3(64 * kBW), lds, st, d, ws, B, Mp);
-      hipLaunchKernelGGL((k_pair_gram_bm<10>), dim3(kGramChunks, Mp / 64), dim3(64), 0, st, d, ws, B, Mp);
-      hipLaunchKernelGGL((k_gram_combine_bm<10>), dim3((B + 255) / 256, 10 + 3 + 3 * d.J + sf::ne_ng(10)),
-                         dim3(256), 0, st, d, ws, B, Mp);
+      launch_residual_bm(d, ws, B, st);
     } else {
       launch_gemm(d, ws, B, st);
 #define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, B, eff_v, st)
@@ -641,7 +672,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     const bool last = it + 1 == o.num_iter;
     if (last && !o.final_adjust) break;  // nothing consumes the re-evaluated mesh
     if (bm) {
-#define SF_CALL_LBS(S_, KW_) launch_lbs_bm<S_, KW_>(d, ws, B, st)
+#define SF_CALL_LBS(S_, KW_) launch_lbs_bm<S_, KW_>(d, ws, B, st, !joints)
       SF_DISPATCH_SKW(d, SF_CALL_LBS);
 #undef SF_CALL_LBS
     } else if (joints) {
@@ -1382,7 +1413,7 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
       case SMPLFIT_KERNEL_POSEDIRS_GEMM: return launch_gemm(d, ws, batch, st, bm);
       case SMPLFIT_KERNEL_PAIR_GRAM:
         if (!bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "pair-Gram kernel: batch-major path not active");
-        hipLaunchKernelGGL((k_pair_gram_bm<10>), dim3(kGramChunks, Mp / 64), dim3(64), 0, st, d, ws, batch, Mp);
+        launch_residual_bm(d, ws, batch, st, 2);
         return 0;
       case SMPLFIT_KERNEL_TRANSPOSE:
         if (!bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "layout kernel: batch-major path not active");
@@ -1397,8 +1428,7 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
         return 0;
       case SMPLFIT_KERNEL_SHAPE_ACCUM: {
         if (bm) {
-          hipLaunchKernelGGL((k_residual_bm<10>), d.lpt ? dim3(Mp / 64, d.ngroups) : dim3(d.ngroups, Mp / 64),
-                             dim3(64 * kBW), kResidualLds, st, d, ws, batch, Mp);
+          launch_residual_bm(d, ws, batch, st, 1);
           return 0;
         }
 #define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, batch, false, st)
@@ -1412,7 +1442,8 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
         return 0;
       case SMPLFIT_KERNEL_LBS_PARTSUM: {
         if (bm) {
-          launch_lbs_bm<10, 4>(d, ws, batch, st);
+          if (d.S == 11) launch_lbs_bm<11, 4>(d, ws, batch, st);
+          else launch_lbs_bm<10, 4>(d, ws, batch, st);
           return 0;
         }
 #define SF_CALL_LBS(S_, KW_) \
