@@ -61,7 +61,7 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
   // A vertex count that is a multiple of the padding (vertex subsets of 1024, 2048, ...) gets one more
   // tile when those kernels apply: measured at B = 16384, 1024 vertices 4.58 -> 4.79 M fits/s, 2048
   // vertices 3.10 -> 3.69 M (512: the wave-per-instance kernels stay ahead, 5.85 vs 5.65 M).
-  if (t.Vp == V && S == 10 && V >= 1024) t.Vp += kVertexPad;
+  if (t.Vp == V && (S == 10 || S == 11) && V >= 1024) t.Vp += kVertexPad;
   // at least one padding row: row P of posedirs holds v_template and the matching pose feature is 1, so
   // the GEMM needs no bias operand (and adds the template last, as the reference does, bodyfitter.py:913-916)
   t.Kp = round_up(t.P + 1, kGemmKPad);
@@ -475,13 +475,22 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
       t.pair_j.push_back(pr.second);
     }
     tof(c1, t.pair_c1); tof(c2, t.pair_c2); tof(c3, t.pair_c3);
-    t.pair_c1x.assign(t.pair_c1.size(), 0.f);
+    const int SE = t.s_even();
+    t.pair_c1x.assign((size_t)np * S * 9 * SE, 0.f);
     for (int p = 0; p < np; ++p)
       for (int aa = 0; aa < 9; ++aa)
         for (int x = 0; x < S; ++x)
           for (int y = 0; y < S; ++y)
-            t.pair_c1x[(((size_t)p * S + x) * 9 + aa) * S + y] = t.pair_c1[(((size_t)p * 9 + aa) * S + x) * S + y];
+            t.pair_c1x[(((size_t)p * S + x) * 9 + aa) * SE + y] = t.pair_c1[(((size_t)p * 9 + aa) * S + x) * S + y];
+    t.pair_c2e.assign((size_t)np * 3 * SE, 0.f);
+    for (int p = 0; p < np; ++p)
+      for (int a = 0; a < 3; ++a)
+        for (int i = 0; i < S; ++i) t.pair_c2e[((size_t)p * 3 + a) * SE + i] = t.pair_c2[((size_t)p * 3 + a) * S + i];
     tof(g0, t.diag_g0); tof(dc2, t.diag_c2); tof(dc3, t.diag_c3);
+    t.diag_c2e.assign((size_t)J * 3 * SE, 0.f);
+    for (int j = 0; j < J; ++j)
+      for (int a = 0; a < 3; ++a)
+        for (int i = 0; i < S; ++i) t.diag_c2e[((size_t)j * 3 + a) * SE + i] = t.diag_c2[((size_t)j * 3 + a) * S + i];
   }
 
   // ---- tiles of the residual kernel: part-aligned over all slots, <= 16 distinct joints ----

@@ -110,7 +110,12 @@ struct HostTables {
   // LOCAL joint slots of the group (byte k = slot of the k-th skinning pair), and the dense weights over
   // the group's joint list
   std::vector<VertexGroup> groups;
-  std::vector<float> pair_c1x;   // pair_c1 re-laid out as (np, S [x], 3 [a], 3 [a'], S [y]) for the batch-major kernel
+  // the batch-major pair-Gram kernel reads rows of shape values as aligned register PAIRS: its copies of the
+  // constants have the y axis padded to an even length SE = S rounded up to 2 (the padding is zero)
+  std::vector<float> pair_c1x;   // pair_c1 re-laid out as (np, S [x], 3 [a], 3 [a'], SE [y])
+  std::vector<float> pair_c2e;   // pair_c2 as (np, 3, SE)
+  std::vector<float> diag_c2e;   // diag_c2 as (J, 3, SE)
+  int s_even() const { return (S + 1) & ~1; }
   // brec row (brec_stride() floats, fetched with scalar loads): [sd_x : S][sd_y : S][sd_z : S][pad to a
   // multiple of 4][KW weights][KW/4 words of local joint slots][pad to 4][dense weights over the group's
   // joint list : kGroupJoints]

@@ -78,7 +78,7 @@ struct DevModel {
   const int32_t *gorder_all, *gorder_used;
   int lpt;
   const float* brec;
-  const float* pair_c1x;
+  const float *pair_c1x, *pair_c2e, *diag_c2e;  // even-stride copies for k_pair_gram_bm (HostTables)
   // per joint: the resP rows (group * kResRec + 16 + 3 * slot) holding its residual moments
   const int32_t *mb_start, *mb_row;
 };
@@ -247,9 +247,7 @@ bool use_bm() {
 bool bm_applies(const DevModel& d) {
   // Vp > V: the batch-major loops run their out-of-range steps on the first padding slot
   // (below ~1000 vertices the staging of a workgroup's joints outweighs its vertex work)
-  // (S = 11 is instantiated and parity-tested, SMPLFIT_BM_KID=1, but its pair-Gram kernel spills: off by default)
-  static const bool kid_bm = [] { const char* e = getenv("SMPLFIT_BM_KID"); return e && e[0] == '1'; }();
-  return use_bm() && d.KW == 4 && (d.S == 10 || (kid_bm && d.S == 11)) && d.ngroups > 0 && d.V >= 1024 && d.Vp > d.V;
+  return use_bm() && d.KW == 4 && (d.S == 10 || d.S == 11) && d.ngroups > 0 && d.V >= 1024 && d.Vp > d.V;
 }
 
 // joint rows of the current rotations, instance-innermost, for k_pair_gram_bm
@@ -277,8 +275,14 @@ void launch_residual_bm_s(const DevModel& d, const Workspace& ws, int B, hipStre
   if (which & 1)
     hipLaunchKernelGGL((k_residual_bm<S>), d.lpt ? dim3(Mp / 64, d.ngroups) : dim3(d.ngroups, Mp / 64),
                        dim3(64 * kBW), kResidualLds, st, d, ws, B, Mp);
-  if (which & 2)
-    hipLaunchKernelGGL((k_pair_gram_bm<S>), dim3(kGramChunks, Mp / 64), dim3(64), 0, st, d, ws, B, Mp);
+  if (which & 2) {
+    if constexpr (S > 10) {  // two launches over the rows of the Gramian (see k_pair_gram_bm)
+      hipLaunchKernelGGL((k_pair_gram_bm<S, 1>), dim3(kGramChunks, Mp / 64), dim3(64), 0, st, d, ws, B, Mp);
+      hipLaunchKernelGGL((k_pair_gram_bm<S, 2>), dim3(kGramChunks, Mp / 64), dim3(64), 0, st, d, ws, B, Mp);
+    } else {
+      hipLaunchKernelGGL((k_pair_gram_bm<S>), dim3(kGramChunks, Mp / 64), dim3(64), 0, st, d, ws, B, Mp);
+    }
+  }
   if (which & 4)
     hipLaunchKernelGGL((k_gram_combine_bm<S>), dim3((B + 255) / 256, S + 3 + 3 * d.J + sf::ne_ng(S)), dim3(256), 0,
                        st, d, ws, B, Mp);
@@ -961,6 +965,8 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
     up(mb_row, &d.mb_row);
     up(t.brec, &d.brec);
     up(t.pair_c1x, &d.pair_c1x);
+    up(t.pair_c2e, &d.pair_c2e);
+    up(t.diag_c2e, &d.diag_c2e);
   }
   sf::JointTabs& jt = d.jt;
   jt.J = t.J; jt.S = t.S; jt.num_levels = t.num_levels(); jt.adj_last_level = t.adj_last_level;
