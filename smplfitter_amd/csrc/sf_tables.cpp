@@ -284,6 +284,8 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
         }
     (void)nslot;
   }
+  t.pdB2.clear();  // built on demand for the device (build_tiled_gemm_images)
+  t.kc32 = 0;
   {
     const int cs = t.cstride();
     auto pack = [&](float* dst, int slot) {  // one vertex record
@@ -580,6 +582,48 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
     t.has_regressor = true;
   }
   return "";
+}
+
+
+// Stage images of posedirs for k_posedirs_gemm_bf16x3_tiled (models with Kp != 208): 94 MB for SMPL-X, so they
+// are built only for a handle that uploads to a device, not by the host-only table builds of the tests.
+void build_tiled_gemm_images(HostTables& t) {
+  const int Vp = t.Vp;
+  t.pdB2.clear();
+  t.kc32 = 0;
+  if (t.Kp != 208 && (3 * Vp) % 128 == 0) {  // stage images for k_posedirs_gemm_bf16x3_tiled
+    const int N = 3 * Vp, Kp = t.Kp, nt128 = N / 128, kc32 = (Kp + 31) / 32;
+    auto bf16_rne = [](float x) -> uint16_t {
+      uint32_t u;
+      std::memcpy(&u, &x, 4);
+      u += 0x7fffu + ((u >> 16) & 1u);
+      return (uint16_t)(u >> 16);
+    };
+    auto bf16_f32 = [](uint16_t h) -> float {
+      const uint32_t u = (uint32_t)h << 16;
+      float f;
+      std::memcpy(&f, &u, 4);
+      return f;
+    };
+    t.kc32 = kc32;
+    const size_t plane = (size_t)128 * 32;  // elements of one plane of a stage
+    t.pdB2.assign((size_t)nt128 * kc32 * 3 * plane, 0);
+    for (int nt = 0; nt < nt128; ++nt)
+      for (int n = 0; n < 128; ++n)
+        for (int k = 0; k < Kp; ++k) {
+          const int col = nt * 128 + n;
+          const float x = t.pdSw[((size_t)(col / 32) * 32 + col % 32) * Kp + k];
+          const uint16_t h = bf16_rne(x);
+          const float r1 = x - bf16_f32(h);
+          const uint16_t m = bf16_rne(r1);
+          const uint16_t l = bf16_rne(r1 - bf16_f32(m));
+          const int kc = k / 32, kk = k % 32, slot = (kk >> 3) ^ ((n >> 2) & 3);
+          const size_t base = ((size_t)nt * kc32 + kc) * 3 * plane + (size_t)n * 32 + slot * 8 + (kk & 7);
+          t.pdB2[base] = h;
+          t.pdB2[base + plane] = m;
+          t.pdB2[base + 2 * plane] = l;
+        }
+  }
 }
 
 }  // namespace sf

@@ -79,6 +79,10 @@ struct HostTables {
   // slot = k / 8 with bit 0 flipped for rows with (n >> 3) & 1 (bank-conflict-free 16-byte LDS reads from
   // unpadded 416-byte rows).  The tile image is copied to LDS verbatim.
   std::vector<uint16_t> pdB;
+  // split-bf16 stage images of posedirs for the tiled GEMM (Kp != 208, e.g. SMPL-X): per 128-column tile and
+  // 32-k stage three planes [128 n][4 slots][8 k] (24 KB), slot = (k >> 3) ^ ((n >> 2) & 3); K padded to kc32 * 32
+  std::vector<uint16_t> pdB2;
+  int kc32 = 0;  // stages of 32 k
   // per-vertex constants packed per 64-vertex tile for cooperative staging through LDS:
   // cstride() floats per vertex = [shapedirs s-major (s*3+c), 3*S | KW weights | KW/4 index words | pad]
   std::vector<float> cpackA;    // (Vp/64, 64, cstride) dense tiles of sorted slots  (shape accumulate)
@@ -142,6 +146,7 @@ struct HostTables {
 };
 
 // Returns "" on success, else an error message (and `unsupported` tells which status to use).
+void build_tiled_gemm_images(HostTables& t);
 std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsupported);
 
 }  // namespace sf

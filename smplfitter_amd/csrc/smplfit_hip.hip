@@ -64,6 +64,8 @@ struct DevModel {
   const int32_t* part_seg_start;  // (J+1) first segment of each part (empty range: unused part)
   const float *vt, *dm, *sd, *wval, *pdSw, *j_template, *cpackA, *cpackB, *gblob;
   const uint16_t* pdB;  // split-bf16 tile images of posedirs (Kp == 208), see HostTables::pdB
+  const uint16_t* pdB2; // split-bf16 stage images for the tiled GEMM (Kp != 208), HostTables::pdB2
+  int kc32;
   const int32_t* gtiles;  // (ngt,3) start, count, part
   int ngt;
   const uint32_t* widx;
@@ -451,6 +453,22 @@ int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, b
     else
       hipLaunchKernelGGL((k_posedirs_gemm_bf16x3<false>), dim3(nchunk, ny), dim3(64 * kGemmWaves), lds, st, ws.rp,
                          d.pdB, ws.vposed, N, per, Mp);
+    return 0;
+  }
+  if (d.Kp != 208 && transposed && d.kc32 > 0 && gemm_bf16x3()) {
+    // tiled split-bf16 GEMM (SMPL-X): the feature images go to ws.vposed, which the batch-major path does not use
+    const int mt = (Mp + 255) / 256, nt128 = N / 128;
+    uint16_t* aimg = reinterpret_cast<uint16_t*>(ws.vposed);
+    hipLaunchKernelGGL(k_split_features, dim3(mt, d.kc32), dim3(256), 0, st, ws.rp, aimg, Mp, d.Kp, d.kc32);
+    static std::once_flag once[16];
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    std::call_once(once[dev_id & 15], [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_posedirs_gemm_bf16x3_tiled),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    hipLaunchKernelGGL(k_posedirs_gemm_bf16x3_tiled, dim3(8 * ((mt + 7) / 8) * nt128), dim3(512), (size_t)2 * kTgStage, st,
+                       aimg, d.pdB2, ws.vpT, N, Mp, mt, d.kc32);
     return 0;
   }
   if (d.Kp == 208) {  // SMPL (J = 24): A-stationary kernel, 104 A registers per lane
@@ -872,6 +890,7 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
     *out = h;
     return SMPLFIT_OK;
   }
+  sf::build_tiled_gemm_images(h->t);  // 94 MB for SMPL-X: device handles only
   const sf::HostTables& t = h->t;
   DevModel& d = h->d;
   d.V = t.V; d.J = t.J; d.S = t.S; d.P = t.P; d.Vp = t.Vp; d.Kp = t.Kp; d.KW = t.KW;
@@ -910,6 +929,9 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
   up(t.widx, &d.widx);
   up(t.pdSw, &d.pdSw);
   up(t.pdB, &d.pdB);
+  up(t.pdB2, &d.pdB2);
+  d.kc32 = t.kc32;
+  std::vector<uint16_t>().swap(h->t.pdB2);  // the host copy of the stage images is not needed any more
   up(t.cpackA, &d.cpackA);
   up(t.cpackB, &d.cpackB);
   up(t.gblob, &d.gblob);
