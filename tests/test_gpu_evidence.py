@@ -198,6 +198,33 @@ def test_gemm_split_precision(model_root, golden, dev, monkeypatch):
     assert util.vertex_l2(om64, out['bf16x3'], out['f32']) < 2e-5
 
 
+@pytest.mark.parametrize('B', [300, 1024])
+def test_gemm_tiled_split_smplx(B, model_root, golden, dev, monkeypatch):
+    """SMPL-X (K = 487): the batch-major path runs the tiled split-bf16 GEMM (k_posedirs_gemm_bf16x3_tiled, feature
+    images by k_split_features); whole fits agree with the fp32-MFMA GEMM (SMPLFIT_GEMM=f32) to the last digits —
+    B = 300 leaves the second 256-instance tile mostly empty, 1024 runs as two chunks."""
+    g = golden('smplx')
+    kind, md = util.load_md(model_root, 'smplx', g)
+    om64, _ = util.make_oracle(md, kind, np.float64)
+    m, f = get_model(model_root, 'smplx', g, dev)
+    tv, tj = make_targets(m, B, 5, dev)
+    out = {}
+    for mode in ('bf16x3', 'f32'):
+        monkeypatch.setenv('SMPLFIT_GEMM', mode)
+        out[mode] = to_np(f.fit(tv, tj, num_iter=3, beta_regularizer=1.0, requested_keys=['pose_rotvecs']))
+    monkeypatch.delenv('SMPLFIT_GEMM')
+    assert np.isfinite(out['bf16x3']['pose_rotvecs']).all()
+    assert np.abs(out['bf16x3']['shape_betas'] - out['f32']['shape_betas']).max() < 5e-5
+    assert np.abs(out['bf16x3']['trans'] - out['f32']['trans']).max() < 2e-6
+    n = min(B, 64)
+    a = {k: v[:n] for k, v in out['bf16x3'].items()}
+    b = {k: v[:n] for k, v in out['f32'].items()}
+    assert util.vertex_l2(om64, a, b) < 6e-5  # the thin-finger fixture amplifies last-digit differences (DESIGN.md 5)
+    a = {k: v[-n:] for k, v in out['bf16x3'].items()}
+    b = {k: v[-n:] for k, v in out['f32'].items()}
+    assert util.vertex_l2(om64, a, b) < 6e-5  # the thin-finger fixture amplifies last-digit differences (DESIGN.md 5)
+
+
 def _sample_rows(B):
     """Instances spread over the batch: both ends, the chunk boundary (B/2), instance-block (64) and
     GEMM-tile (128) boundaries, and a seeded scatter."""
