@@ -249,7 +249,9 @@ bool use_bm() {
 bool bm_applies(const DevModel& d) {
   // Vp > V: the batch-major loops run their out-of-range steps on the first padding slot
   // (below ~1000 vertices the staging of a workgroup's joints outweighs its vertex work)
-  return use_bm() && d.KW == 4 && (d.S == 10 || d.S == 11) && d.ngroups > 0 && d.V >= 1024 && d.Vp > d.V;
+  // the layout kernel's slab sums use ws.resP as scratch: (slabs x 3) rows must fit its (groups x kResRec) rows
+  const bool slab_fit = 3 * ((d.V + kSlabV - 1) / kSlabV) <= d.ngroups * kResRec;
+  return use_bm() && d.KW == 4 && (d.S == 10 || d.S == 11) && d.ngroups > 0 && d.V >= 1024 && d.Vp > d.V && slab_fit;
 }
 
 // joint rows of the current rotations, instance-innermost, for k_pair_gram_bm
