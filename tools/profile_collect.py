@@ -80,6 +80,11 @@ for k in sorted(set(fetch) | set(write)):
                    launches_in_pass=len(f_kib))
 # launches per fit (num_iter = 3) from the one-chunk trace
 rows = trace_rows(f'{src}/trace1')
+# only the fits themselves: bench.py's roofline leg (smplfit_time_kernel_f32: repeated single-kernel launches) and
+# its round-trip forward come after the last fit's epilogue
+last_fit_end = max((e for s, e, n in rows if short(n) == 'k_refine_epilogue'), default=None)
+if last_fit_end is not None:
+    rows = [r for r in rows if r[0] <= last_fit_end]
 cnt = collections.Counter(short(n) for s, e, n in rows)
 fits = max(1, cnt.get('k_refine_epilogue', 1))
 per_fit = 0
