@@ -266,7 +266,7 @@ void launch_layout_bm(const DevModel& d, const float* tv, const float* tj, const
   const int Mp = (int)align_up((size_t)B, 128), nslab = (d.V + kSlabV - 1) / kSlabV;
   hipLaunchKernelGGL(k_layout_targets, dim3(nslab, Mp / 64), dim3(256), (size_t)64 * kSlabRow * 4, st, d, tv, ws.tT,
                      ws.resP, B, Mp);
-  hipLaunchKernelGGL(k_mean_finish, dim3(Mp / 64), dim3(256), 0, st, d, tj, ws.resP, ws, B, Mp, nslab);
+  hipLaunchKernelGGL(k_mean_finish, dim3(Mp / 64), dim3(64 * kMeanWaves), 0, st, d, tj, ws.resP, ws, B, Mp, nslab);
   hipLaunchKernelGGL(k_template_partsum_bm, d.lpt ? dim3(Mp / 64, d.ngroups_used) : dim3(d.ngroups_used, Mp / 64),
                      dim3(64 * kBW), 0, st, d, ws, B, Mp);
   hipLaunchKernelGGL(k_psum_combine, dim3((B + 255) / 256, d.J), dim3(256), 0, st, d, ws, B, Mp);
