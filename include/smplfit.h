@@ -82,6 +82,8 @@ typedef struct smplfit_info {
   int32_t num_fk_levels;
   int32_t adj_last_level;
   int32_t has_device;
+  int32_t gemm_vgprs;          /* registers per lane of the split-bf16 GEMM kernels as built (0 without a device):
+                                  they must own whole CUs (>= 256); below that the fp32-MFMA GEMM runs instead  */
 } smplfit_info;
 int smplfit_get_info(const smplfit_handle* h, smplfit_info* info);
 
@@ -134,6 +136,27 @@ int smplfit_forward_f32(const smplfit_handle* h, const float* pose_rotvecs,
                         float* joints,
                         float* orientations, void* workspace, size_t workspace_bytes,
                         void* hip_stream);
+
+/* The general form of smplfit_forward_f32: additionally rel_rotmats (B,J,3,3), the relative rotation matrices of
+ * BodyModel.forward (pt/bodymodel.py:230-234: global rotations by the kinematic chain, inside the joint kernel).
+ * Exactly one of pose_rotvecs / glob_rotmats / rel_rotmats non-NULL (all NULL: rest pose).  Zero-initialise. */
+typedef struct smplfit_forward_args {
+  const float* pose_rotvecs;   /* (B,3J) or NULL */
+  const float* glob_rotmats;   /* (B,J,3,3) or NULL */
+  const float* rel_rotmats;    /* (B,J,3,3) or NULL */
+  const float* shape_betas;    /* (B,num_betas_given) or NULL */
+  int32_t num_betas_given;
+  const float* trans;          /* (B,3) or NULL */
+  const float* kid_factor;     /* (B) or NULL */
+  int32_t batch;
+  float* vertices;             /* out (B,V,3) or NULL */
+  float* joints;               /* out (B,J,3) */
+  float* orientations;         /* out (B,J,3,3) or NULL */
+  void* workspace;
+  size_t workspace_bytes;
+  void* hip_stream;
+} smplfit_forward_args;
+int smplfit_forward_ex_f32(const smplfit_handle* h, const smplfit_forward_args* args);
 
 /* BodyFitter.fit with a warm start (pt/bodyfitter.py:363-382): smplfit_fit_f32 plus
  *   initial_pose_rotvecs (B,3J) or NULL, initial_shape_betas (B,num_initial_betas) or NULL,
@@ -284,6 +307,67 @@ typedef struct smplfit_shape_solve_args {
   void* share_user;
 } smplfit_shape_solve_args;
 int smplfit_shape_solve_ex_f32(const smplfit_handle* h, const smplfit_shape_solve_args* args);
+
+/*
+ * Topology transfer — BodyConverter.convert_vertices (pt/bodyconverter.py:128-149): out = M in with the sparse
+ * (V_out x V_in) matrix BodyConverter.__init__ loads (pt/bodyconverter.py:31-47; the first V_in columns of the
+ * official *_deftrafo_setup.pkl matrix, common.py:425-429).  smplfit_transfer_create copies a CSR matrix (HOST
+ * pointers: indptr (V_out + 1), indices / values (nnz)) and uploads it to the current device (flags =
+ * SMPLFIT_CREATE_HOST_ONLY: no upload, for tests).  smplfit_transfer_f32: in_vertices (B,V_in,3) ->
+ * out_vertices (B,V_out,3), device pointers; the entries of a row are added in CSR order, as the reference's sparse
+ * product does.
+ */
+typedef struct smplfit_transfer smplfit_transfer;
+int smplfit_transfer_create(int32_t num_vertices_in, int32_t num_vertices_out, const int32_t* indptr,
+                            const int32_t* indices, const float* values, int flags, smplfit_transfer** out);
+void smplfit_transfer_destroy(smplfit_transfer* t);
+int smplfit_transfer_f32(const smplfit_transfer* t, const float* in_vertices, int batch, float* out_vertices,
+                         void* hip_stream);
+
+/*
+ * BodyConverter.convert, default branch (pt/bodyconverter.py:49-126: forward of the input model :86, convert_vertices
+ * :87, fit of the output model with enable_kid :110-117), as ONE call that keeps every intermediate in the kernels'
+ * own instance-innermost layout: the input model's posed vertices never leave their stream buffer, the transfer writes
+ * the output model's target stream directly (no (B,V,3) intermediates, no layout pass).
+ *   smplfit_convert_plan_create(in, out, transfer, &plan): `in` = handle of body_model_in (no kid unknown), `out` =
+ *   handle of body_model_out (normally created with enable_kid, as BodyConverter's fitter is), `transfer` = NULL for
+ *   models of one topology (identity).  Returns SMPLFIT_ERR_UNSUPPORTED when one of the models is outside what the
+ *   batch-major kernels take — the caller then runs smplfit_forward_f32 + smplfit_transfer_f32 + smplfit_fit_f32.
+ *   The plan borrows the two handles (keep them alive) and owns its re-indexed copy of the matrix.
+ *   smplfit_convert_f32: inputs pose_rotvecs (B,3 J_in), shape_betas (B,num_betas_given) or NULL, trans (B,3) or NULL
+ *   of the INPUT model (its mesh is evaluated without kid_factor, as the reference does); the fit options of
+ *   smplfit_fit_f32 (the reference passes beta_regularizer = 0, final_adjust_rots = 0, kid_regularizer = 1e9 or 0);
+ *   outputs as smplfit_fit_f32 for the OUTPUT model.  Workspace: smplfit_convert_workspace_bytes(plan, batch).
+ */
+typedef struct smplfit_convert_plan smplfit_convert_plan;
+int smplfit_convert_plan_create(const smplfit_handle* in, const smplfit_handle* out, const smplfit_transfer* transfer,
+                                smplfit_convert_plan** plan);
+void smplfit_convert_plan_destroy(smplfit_convert_plan* plan);
+size_t smplfit_convert_workspace_bytes(const smplfit_convert_plan* plan, int batch);
+typedef struct smplfit_convert_args {
+  const float* pose_rotvecs;         /* (B,3 J_in) */
+  const float* shape_betas;          /* (B,num_betas_given) or NULL */
+  int32_t num_betas_given;
+  const float* trans;                /* (B,3) or NULL */
+  int32_t batch, num_iter;
+  float beta_regularizer, beta_regularizer2, kid_regularizer;
+  int32_t final_adjust_rots;
+  float* out_pose_rotvecs;           /* (B,3 J_out) */
+  float* out_shape_betas;            /* (B,S_out) */
+  float* out_trans;                  /* (B,3) */
+  float* out_kid_factor;             /* (B) or NULL */
+  float* out_orientations;           /* (B,J_out,3,3) or NULL */
+  float* out_relative_orientations;  /* (B,J_out,3,3) or NULL */
+  void* workspace;
+  size_t workspace_bytes;
+  void* hip_stream;
+} smplfit_convert_args;
+int smplfit_convert_f32(const smplfit_convert_plan* plan, const smplfit_convert_args* args);
+
+/* Re-reads the SMPLFIT_* tuning variables (INTEGRATION.md lists them).  They are read once, at first use; tests and
+ * the A/B tools that switch kernel paths inside one process call this after changing the environment.  Not to be
+ * called while other threads are inside the library. */
+int smplfit_reload_options(void);
 
 /* Measurement hook (bench.py's roofline leg): launches ONE kernel of the fit `reps` times on
  * `hip_stream` between two HIP events recorded on that same stream and returns the average

@@ -35,7 +35,10 @@ EXPORTED_SYMBOLS = [
     'smplfit_get_info', 'smplfit_get_table', 'smplfit_workspace_bytes', 'smplfit_fit_f32',
     'smplfit_forward_f32', 'smplfit_part_rotations_f32', 'smplfit_shape_solve_f32',
     'smplfit_shape_solve_ex_f32', 'smplfit_fit_known_shape_f32', 'smplfit_fit_warm_f32', 'smplfit_fit_ex_f32',
-    'smplfit_time_kernel_f32', 'smplfit_primitives_f32',
+    'smplfit_time_kernel_f32', 'smplfit_primitives_f32', 'smplfit_forward_ex_f32',
+    'smplfit_transfer_create', 'smplfit_transfer_destroy', 'smplfit_transfer_f32',
+    'smplfit_convert_plan_create', 'smplfit_convert_plan_destroy', 'smplfit_convert_workspace_bytes',
+    'smplfit_convert_f32', 'smplfit_reload_options',
 ]  # fmt: skip
 
 _fp = C.POINTER(C.c_float)
@@ -80,6 +83,30 @@ class ShapeSolveArgs(C.Structure):
     ]
 
 
+class ForwardArgs(C.Structure):
+    """smplfit_forward_args (include/smplfit.h)."""
+    _fields_ = [
+        ('pose_rotvecs', C.c_void_p), ('glob_rotmats', C.c_void_p), ('rel_rotmats', C.c_void_p),
+        ('shape_betas', C.c_void_p), ('num_betas_given', C.c_int32), ('trans', C.c_void_p),
+        ('kid_factor', C.c_void_p), ('batch', C.c_int32), ('vertices', C.c_void_p), ('joints', C.c_void_p),
+        ('orientations', C.c_void_p), ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t),
+        ('hip_stream', C.c_void_p),
+    ]
+
+
+class ConvertArgs(C.Structure):
+    """smplfit_convert_args (include/smplfit.h)."""
+    _fields_ = [
+        ('pose_rotvecs', C.c_void_p), ('shape_betas', C.c_void_p), ('num_betas_given', C.c_int32),
+        ('trans', C.c_void_p), ('batch', C.c_int32), ('num_iter', C.c_int32),
+        ('beta_regularizer', C.c_float), ('beta_regularizer2', C.c_float), ('kid_regularizer', C.c_float),
+        ('final_adjust_rots', C.c_int32), ('out_pose_rotvecs', C.c_void_p), ('out_shape_betas', C.c_void_p),
+        ('out_trans', C.c_void_p), ('out_kid_factor', C.c_void_p), ('out_orientations', C.c_void_p),
+        ('out_relative_orientations', C.c_void_p), ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t),
+        ('hip_stream', C.c_void_p),
+    ]
+
+
 class ModelDesc(C.Structure):
     _fields_ = [
         ('num_vertices', C.c_int32),
@@ -106,7 +133,7 @@ class Info(C.Structure):
         (n, C.c_int32)
         for n in (
             'num_vertices', 'num_joints', 'num_betas', 'has_kid', 'padded_vertices', 'num_used_vertices',
-            'skin_width', 'num_segments', 'num_fk_levels', 'adj_last_level', 'has_device',
+            'skin_width', 'num_segments', 'num_fk_levels', 'adj_last_level', 'has_device', 'gemm_vgprs',
         )
     ]  # fmt: skip
 
@@ -167,6 +194,24 @@ def load():
     lib.smplfit_time_kernel_f32.restype = i32
     lib.smplfit_primitives_f32.argtypes = [i32, vp, vp, vp, i32, vp]
     lib.smplfit_primitives_f32.restype = i32
+    lib.smplfit_forward_ex_f32.argtypes = [vp, C.POINTER(ForwardArgs)]
+    lib.smplfit_forward_ex_f32.restype = i32
+    lib.smplfit_transfer_create.argtypes = [i32, i32, _ip, _ip, _fp, i32, C.POINTER(vp)]
+    lib.smplfit_transfer_create.restype = i32
+    lib.smplfit_transfer_destroy.argtypes = [vp]
+    lib.smplfit_transfer_destroy.restype = None
+    lib.smplfit_transfer_f32.argtypes = [vp, vp, i32, vp, vp]
+    lib.smplfit_transfer_f32.restype = i32
+    lib.smplfit_convert_plan_create.argtypes = [vp, vp, vp, C.POINTER(vp)]
+    lib.smplfit_convert_plan_create.restype = i32
+    lib.smplfit_convert_plan_destroy.argtypes = [vp]
+    lib.smplfit_convert_plan_destroy.restype = None
+    lib.smplfit_convert_workspace_bytes.argtypes = [vp, i32]
+    lib.smplfit_convert_workspace_bytes.restype = sz
+    lib.smplfit_convert_f32.argtypes = [vp, C.POINTER(ConvertArgs)]
+    lib.smplfit_convert_f32.restype = i32
+    lib.smplfit_reload_options.argtypes = []
+    lib.smplfit_reload_options.restype = i32
     _lib = lib
     return lib
 
@@ -256,6 +301,73 @@ class Handle:
         if getattr(self, '_h', None) is not None and self._h.value:
             load().smplfit_destroy(self._h)
             self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def reload_options():
+    """Re-read the SMPLFIT_* tuning variables (they are read once, at first use): for tests and A/B tools that
+    switch kernel paths inside one process."""
+    check(load().smplfit_reload_options())
+
+
+class Transfer:
+    """Owns a ``smplfit_transfer*``: the (V_out x V_in) CSR topology-transfer matrix on the current device."""
+
+    def __init__(self, num_vertices_in: int, num_vertices_out: int, indptr, indices, values, host_only: bool = False):
+        lib = load()
+        ip = np.ascontiguousarray(indptr, dtype=np.int32)
+        ix = np.ascontiguousarray(indices, dtype=np.int32)
+        va = np.ascontiguousarray(values, dtype=np.float32)
+        if ip.shape != (num_vertices_out + 1,) or ix.shape != va.shape or ix.ndim != 1 or int(ip[-1]) != ix.shape[0]:
+            raise ValueError('Transfer: indptr / indices / values do not describe a (V_out x V_in) CSR matrix')
+        self.shape = (int(num_vertices_out), int(num_vertices_in))
+        self._t = C.c_void_p()
+        check(lib.smplfit_transfer_create(
+            int(num_vertices_in), int(num_vertices_out), ip.ctypes.data_as(_ip), ix.ctypes.data_as(_ip),
+            va.ctypes.data_as(_fp), SMPLFIT_CREATE_HOST_ONLY if host_only else 0, C.byref(self._t)))
+
+    @property
+    def ptr(self):
+        return self._t
+
+    def close(self):
+        if getattr(self, '_t', None) is not None and self._t.value:
+            load().smplfit_transfer_destroy(self._t)
+            self._t = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ConvertPlan:
+    """Owns a ``smplfit_convert_plan*`` and keeps the two handles (and the matrix) it borrows alive.  Raises
+    ``NotImplementedError`` when the fused conversion does not apply to the two models."""
+
+    def __init__(self, h_in: Handle, h_out: Handle, transfer: 'Transfer | None'):
+        self._keep = (h_in, h_out, transfer)
+        self._p = C.c_void_p()
+        check(load().smplfit_convert_plan_create(h_in.ptr, h_out.ptr, transfer.ptr if transfer is not None else None,
+                                                 C.byref(self._p)))
+
+    @property
+    def ptr(self):
+        return self._p
+
+    def workspace_bytes(self, batch: int) -> int:
+        return int(load().smplfit_convert_workspace_bytes(self._p, int(batch)))
+
+    def close(self):
+        if getattr(self, '_p', None) is not None and self._p.value:
+            load().smplfit_convert_plan_destroy(self._p)
+            self._p = C.c_void_p()
 
     def __del__(self):
         try:

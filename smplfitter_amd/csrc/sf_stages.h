@@ -828,14 +828,18 @@ template <class Ctx>
 SF_HD void forward_joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh,
                                const float* pose_rotvecs, const float* glob_in, const float* betas,
                                int nb, const float* kid, const float* trans, float* rp_out, float* jd_out,
-                               float* joints_out, float* orient_out) {
+                               float* joints_out, float* orient_out, const float* rel_in = nullptr) {
+  // rel_in (J,3,3): relative rotation matrices given directly (forward's rel_rotmats, bodymodel.py:230-234) — the
+  // same kinematic chain as pose_rotvecs without the exponential map
   const int J = tb.J, S = tb.S, S1 = S + 1;
   if (glob_in) {
     SF_FOR(k, J * 9) sh.G[k] = glob_in[k];
   } else {
     SF_FOR(j, J) {
       float m[9];
-      if (pose_rotvecs) {
+      if (rel_in) {
+        for (int k = 0; k < 9; ++k) m[k] = rel_in[j * 9 + k];
+      } else if (pose_rotvecs) {
         rotvec2mat(pose_rotvecs + j * 3, m);
       } else {
         m3_identity(m);

@@ -211,6 +211,7 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
   t.pdT.assign((size_t)t.Kp * 3 * Vp, 0.f);
   const int half_k = t.Kp / 2;
   auto kpos = [&](int p) { return (p & 1) * half_k + (p >> 1); };  // == sf::rp_pos
+  t.wsum_dev = 0.f;
   for (int i = 0; i < V; ++i) {
     const int v = order[i];
     const float* w = d.weights + (size_t)v * J;
@@ -224,6 +225,7 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
         ++k;
       }
     }
+    t.wsum_dev = std::max(t.wsum_dev, std::fabs(wsum - 1.f));
     // padded pairs keep weight 0 and point at the vertex's own part (an LDS address other lanes
     // of the wave already read -> broadcast)
     for (; k < t.KW; ++k)

@@ -44,6 +44,9 @@ struct HostTables {
                                    // are built for 10 / 16 betas, a model with fewer is padded up (unit ridge)
   int num_betas() const { return S - n_kid - n_pad; }  // the caller's betas
   int Vp = 0, Kp = 0, KW = 4;
+  // max over vertices of |sum of skinning weights - 1|: the batch-major residual kernel derives the residual sum
+  // from the per-joint moments, which is exact only for normalised weights (the other kernels keep the sum explicitly)
+  float wsum_dev = 0.f;
   bool smpl_family = false;
   bool has_regressor = false;
 

@@ -66,6 +66,7 @@ struct DevModel {
   const uint16_t* pdB;  // split-bf16 tile images of posedirs (Kp == 208), see HostTables::pdB
   const uint16_t* pdB2; // split-bf16 stage images for the tiled GEMM (Kp != 208), HostTables::pdB2
   int kc32;
+  int gemm_exclusive;  // the split-bf16 GEMM kernels own whole CUs (smplfit_handle::gemm_vgprs >= 256)
   const int32_t* gtiles;  // (ngt,3) start, count, part
   int ngt;
   const uint32_t* widx;
@@ -96,11 +97,32 @@ struct smplfit_handle {
   DevModel d{};
   std::vector<void*> allocs;
   bool has_device = false;
+  // registers per lane the split-bf16 GEMM kernels were built with (hipFuncGetAttributes at create).  They must own
+  // the whole register file of a CU (256 x 8 waves, see k_posedirs_gemm_bf16x3 "exclusive CU"); if a toolchain ever
+  // allocates fewer, the fp32-MFMA GEMM is used instead
+  int gemm_vgprs = 0;
   // fork/join resources of the chunked fit (see smplfit_fit_f32); guarded by `mu`
   hipStream_t side[kMaxChunks - 1] = {};
   hipEvent_t ev_fork = nullptr, ev_join[kMaxChunks - 1] = {};
   bool have_streams = false;
   mutable std::mutex mu;
+};
+
+// Topology-transfer matrix (BodyConverter's vertex_converter_csr, pt/bodyconverter.py:31-47): host + device CSR.
+struct smplfit_transfer {
+  int v_in = 0, v_out = 0;
+  std::vector<int32_t> indptr, indices;
+  std::vector<float> values;
+  int32_t *d_indptr = nullptr, *d_indices = nullptr;
+  float* d_values = nullptr;
+};
+
+// Fused conversion plan (smplfit_convert_f32): the transfer matrix re-indexed to the sorted slots of the two models.
+struct smplfit_convert_plan {
+  const smplfit_handle *in = nullptr, *out = nullptr;
+  int nslab = 0;
+  int32_t *d_oslot = nullptr, *d_start = nullptr, *d_islot = nullptr;
+  float* d_w = nullptr;
 };
 
 namespace {
@@ -172,11 +194,14 @@ struct Workspace {
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w) {
+// fwd_only: the slice a batch-major forward of this model needs (the input side of a fused conversion, see
+// smplfit_convert_f32): pose features, joint rows, shape / translation and the instance-innermost v_posed buffer.
+size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w, bool fwd_only = false) {
   const size_t Mp = align_up((size_t)B, 128);
   const size_t Vp = t.Vp, J = t.J, S = t.S, NE1 = t.ne() + 1;
   size_t off = 0;
-  auto take = [&](size_t bytes) {
+  auto take = [&](size_t bytes, bool fwd = false) {  // fwd: also part of the forward-only slice
+    if (fwd_only && !fwd) return (char*)nullptr;
     size_t o = off;
     off = align_up(off + bytes, 256);
     return base ? base + o : nullptr;
@@ -184,36 +209,39 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w) {
   Workspace ws;
   ws.tvs = (float*)take((size_t)B * 3 * Vp * 4);
   ws.vws = (float*)take((size_t)B * Vp * 4);
-  ws.vposed = (float*)take(Mp * 3 * Vp * 4);
-  ws.rp = (float*)take(Mp * t.Kp * 4);
+  // instance-major GEMM output; on the batch-major path of a model with Kp != 208 it holds the split feature
+  // images of the tiled GEMM instead (k_split_features: 48 KB per 256-instance tile and 32-k stage)
+  ws.vposed = (float*)take(fwd_only ? (t.Kp != 208 ? (Mp + 255) / 256 * (size_t)((t.Kp + 31) / 32) * 49152 : 0)
+                                    : Mp * 3 * Vp * 4, true);
+  ws.rp = (float*)take(Mp * t.Kp * 4, true);
   ws.mean = (float*)take((size_t)B * 3 * 4);
   ws.tjc = (float*)take((size_t)B * J * 3 * 4);
   ws.psum = (float*)take((size_t)B * J * sf::kPsum * 4);
   ws.G = (float*)take((size_t)B * J * 9 * 4);
-  ws.jd = (float*)take((size_t)B * J * sf::jd_stride(S) * 4);
+  ws.jd = (float*)take((size_t)B * J * sf::jd_stride(S) * 4, true);
   ws.pext = (float*)take((size_t)B * J * 3 * (S + 1) * 4);
   ws.gramj = (float*)take((size_t)B * NE1 * 4);
   ws.gramv = (double*)take((size_t)B * NE1 * 8);
-  ws.beta = (float*)take((size_t)B * S * 4);
-  ws.trans = (float*)take((size_t)B * 3 * 4);
-  ws.jb = (float*)take((size_t)B * J * 4 * 4);
-  ws.rjoints = (float*)take((size_t)B * J * 3 * 4);
+  ws.beta = (float*)take((size_t)B * S * 4, true);
+  ws.trans = (float*)take((size_t)B * 3 * 4, true);
+  ws.jb = (float*)take((size_t)B * J * 4 * 4, true);
+  ws.rjoints = (float*)take((size_t)B * J * 3 * 4, true);
   ws.rverts = (float*)take((size_t)B * 3 * Vp * 4);
   ws.tjreg = (float*)take((size_t)B * J * 3 * 4);
   ws.rjreg = (float*)take((size_t)B * J * 3 * 4);
   ws.mbj = (float*)take((size_t)B * J * 3 * 4);
   ws.scale = (float*)take((size_t)B * 4);
-  ws.regref = (float*)take((size_t)B * S * 4);
+  ws.regref = (float*)take((size_t)B * S * 4, true);
   ws.cen = (double*)take(((size_t)B + 1) * (S * S + S) * 8);
   ws.vextra = (float*)take((size_t)B * 32 * 4);
   ws.beta_out = (float*)take((size_t)B * S * 4);
   ws.tjs = (float*)take((size_t)B * J * 3 * 4);
-  ws.vpT = (float*)take(Mp * 3 * Vp * 4);
+  ws.vpT = (float*)take(Mp * 3 * Vp * 4, true);
   ws.tT = (float*)take(Mp * 3 * Vp * 4);
   ws.psumP = (float*)take((size_t)t.groups.size() * 16 * Mp * 4);
   ws.resP = (float*)take((size_t)t.groups.size() * (16 + 3 * sf::kGroupJoints) * Mp * 4);
   ws.gramP = (float*)take((size_t)32 * (NE1 - 1) * Mp * 4);  // kGramChunks x NG (<= NE) x Mp
-  ws.jdT = (float*)take(Mp * align_up((size_t)J * sf::jd_stride(S), 64) * 4);
+  ws.jdT = (float*)take(Mp * align_up((size_t)J * sf::jd_stride(S), 64) * 4, true);
   if (w) *w = ws;
   return off;
 }
@@ -225,34 +253,64 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w) {
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// Tuning switches.  Every SMPLFIT_* environment variable the launch code honours is read ONCE (first use) into
+// this struct — no getenv on the launch path; smplfit_reload_options() re-reads them (tests and the A/B tools
+// switch paths inside one process).  INTEGRATION.md documents each of them.
+// ------------------------------------------------------------------------------------------------
+struct Tuning {
+  bool bm = true;          // SMPLFIT_BM=0: wave-per-instance vertex kernels everywhere
+  bool gemm_f32 = false;   // SMPLFIT_GEMM=f32: fp32-MFMA posedirs GEMM instead of the split-bf16 one
+  bool pair_form = false;  // SMPLFIT_SHAPE_FORM=pair: pair-Gram form on the wave-per-instance path
+  bool k0_two = true;      // SMPLFIT_K0_TWO=0: K0 stages the whole row (one workgroup per CU)
+  int chunks = 2;          // SMPLFIT_CHUNKS=1..4: concurrent batch chunks of one fit call
+  int gemm_nchunk = 0;     // SMPLFIT_GEMM_NCHUNK: column-tile chunks of the split-bf16 GEMM (0 = automatic)
+  int gemm_lds_kb = 0;     // SMPLFIT_GEMM_LDS_KB: LDS request of the fp32 A-stationary GEMM (occupancy experiments)
+  int lpt = 1;             // SMPLFIT_LPT=0: vertex groups launched in table order (read at smplfit_create)
+};
+Tuning g_tune;
+std::once_flag g_tune_once;
+void load_tuning() {
+  Tuning t;
+  auto env = [](const char* n) { return getenv(n); };
+  if (const char* e = env("SMPLFIT_BM")) t.bm = e[0] != '0';
+  if (const char* e = env("SMPLFIT_GEMM")) t.gemm_f32 = e[0] == 'f';
+  if (const char* e = env("SMPLFIT_SHAPE_FORM")) t.pair_form = std::string(e) == "pair";
+  if (const char* e = env("SMPLFIT_K0_TWO")) t.k0_two = e[0] != '0';
+  if (const char* e = env("SMPLFIT_CHUNKS")) t.chunks = std::min(std::max(atoi(e), 1), 4);
+  if (const char* e = env("SMPLFIT_GEMM_NCHUNK")) t.gemm_nchunk = std::max(1, atoi(e));
+  if (const char* e = env("SMPLFIT_GEMM_LDS_KB")) t.gemm_lds_kb = atoi(e);
+  if (const char* e = env("SMPLFIT_LPT")) t.lpt = atoi(e);
+  g_tune = t;
+}
+const Tuning& tune() {
+  std::call_once(g_tune_once, load_tuning);
+  return g_tune;
+}
+
 // The unit-weight vertex block has two implementations:
 //   direct (default): k_shape_accum accumulates G, r, Sb per vertex (VALU-bound);
 //   pair  (SMPLFIT_SHAPE_FORM=pair): k_residual + k_pair_gram — 4x fewer per-vertex FLOPs, parity-tested,
-//          but not yet faster: the residual pass is bound by the memory system.
-bool use_pair_form() {
-  static const bool pair = [] {
-    const char* e = getenv("SMPLFIT_SHAPE_FORM");
-    return e && std::string(e) == "pair";
-  }();
-  return pair;
-}
+//          but not faster on wave-per-instance kernels (the batch-major path always uses the pair form).
+bool use_pair_form() { return tune().pair_form; }
 
-// Batch-major vertex kernels: the default whenever they apply (unit vertex weights, target joints
-// given, 10 betas, 4 skinning pairs per vertex); SMPLFIT_BM=0 selects the
+// Batch-major vertex kernels: the default whenever they apply (bm_applies); SMPLFIT_BM=0 selects the
 // wave-per-instance kernels everywhere (they also serve every other configuration).
-bool use_bm() {
-  const char* e = getenv("SMPLFIT_BM");
-  return !(e && e[0] == '0');
-}
+bool use_bm() { return tune().bm; }
 // Small vertex subsets stay on the wave-per-instance kernels: the pair-Gram and combine passes cost the
 // same per instance whatever V is (measured at V = 1024, B = 16384: 4.15 M fits/s batch-major vs 4.63 M).
 bool bm_applies(const DevModel& d) {
+  // (normalised skinning weights are checked where the handle is at hand: bm_applies(const smplfit_handle*))
   // Vp > V: the batch-major loops run their out-of-range steps on the first padding slot
   // (below ~1000 vertices the staging of a workgroup's joints outweighs its vertex work)
   // the layout kernel's slab sums use ws.resP as scratch: (slabs x 3) rows must fit its (groups x kResRec) rows
   const bool slab_fit = 3 * ((d.V + kSlabV - 1) / kSlabV) <= d.ngroups * kResRec;
   return use_bm() && d.KW == 4 && (d.S == 10 || d.S == 11) && d.ngroups > 0 && d.V >= 1024 && d.Vp > d.V && slab_fit;
 }
+
+// The batch-major residual kernel derives sum_v b_v from the per-joint moments: exact only when every vertex's
+// skinning weights sum to one (sf::HostTables::wsum_dev) — other models stay on the wave-per-instance kernels.
+bool bm_applies(const smplfit_handle* h) { return bm_applies(h->d) && h->t.wsum_dev <= 1e-5f; }
 
 // joint rows of the current rotations, instance-innermost, for k_pair_gram_bm
 void launch_jd_transpose(const DevModel& d, const Workspace& ws, int B, hipStream_t st) {
@@ -362,8 +420,7 @@ void launch_center_sort(const DevModel& d, const float* tv, const float* tj, con
   int VL = d.V;
   {
     const int cap = ((80 * 1024 - 64 * 4) / 12) & ~1;
-    static const bool two = [] { const char* e = getenv("SMPLFIT_K0_TWO"); return !(e && e[0] == '0'); }();
-    if (two && d.V > cap && d.V - cap <= d.V / 16) VL = cap;
+    if (tune().k0_two && d.V > cap && d.V - cap <= d.V / 16) VL = cap;
   }
   const size_t lds_row = ((size_t)((3 * VL + 3) & ~3) + 64) * 4;
   if (lds_row <= 160 * 1024) {
@@ -404,7 +461,7 @@ void launch_center_sort(const DevModel& d, const float* tv, const float* tj, con
                      "unsupported (shape unknowns, skinning width) combination"); \
   } while (0)
 
-size_t chunked_workspace_bytes(const sf::HostTables& t, int batch);
+size_t chunked_workspace_bytes(const sf::HostTables& t, int batch, const sf::HostTables* tin = nullptr);
 
 int check_common(const smplfit_handle* h, int batch, void* workspace, size_t workspace_bytes) {
   if (!h) return fail(SMPLFIT_ERR_BAD_ARG, "null handle");
@@ -417,18 +474,15 @@ int check_common(const smplfit_handle* h, int batch, void* workspace, size_t wor
   return 0;
 }
 
-// Arithmetic of the posedirs contraction (SMPL, Kp == 208): "bf16x3" (default) runs it on the bf16 matrix
-// cores with every fp32 operand split error-free into three bf16 terms (6 products per k, fp32 accumulate:
-// fp32-equivalent accuracy, see k_posedirs_gemm_bf16x3); "f32" (SMPLFIT_GEMM=f32) uses the fp32 MFMA, which
-// on gfx950 shares the vector ALUs with ordinary VALU work.  Read at every launch (tests switch it).
-bool gemm_bf16x3() {
-  const char* e = getenv("SMPLFIT_GEMM");
-  return !(e && e[0] == 'f');
-}
+// Arithmetic of the posedirs contraction: "bf16x3" (default) runs it on the bf16 matrix cores with every fp32
+// operand split error-free into three bf16 terms (6 products per k, fp32 accumulate: fp32-equivalent accuracy,
+// see k_posedirs_gemm_bf16x3); "f32" (SMPLFIT_GEMM=f32) uses the fp32 MFMA, which on gfx950 shares the vector
+// ALUs with ordinary VALU work.
+bool gemm_bf16x3() { return !tune().gemm_f32; }
 
 int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, bool transposed = false) {
   const int Mp = (int)align_up((size_t)B, 128), N = 3 * d.Vp;
-  if (d.Kp == 208 && gemm_bf16x3()) {
+  if (d.Kp == 208 && gemm_bf16x3() && d.gemm_exclusive) {
     // Workgroup = 8 waves x 32 instances = one whole CU (see k_posedirs_gemm_bf16x3).  XCD-aware tiling: block
     // id = y * nchunk + x runs on XCD id % 8, so with nchunk a multiple of 8 a tile chunk x lives on ONE XCD,
     // and with nchunk * ny ~ 512 (two residency rounds) the instance blocks y of a chunk walk its tiles
@@ -436,7 +490,7 @@ int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, b
     // per launch instead of once per instance block (FETCH_SIZE: 444 -> 72 MB per launch at B = 4096).
     const int ntiles = N / 32, ny = (Mp + 32 * kGemmWaves - 1) / (32 * kGemmWaves);
     int nchunk = std::max(8, (2 * 256 / ny + 4) / 8 * 8);
-    if (const char* e = getenv("SMPLFIT_GEMM_NCHUNK")) nchunk = std::max(1, atoi(e));
+    if (tune().gemm_nchunk > 0) nchunk = tune().gemm_nchunk;
     nchunk = std::min(nchunk, ntiles);
     const int per = (ntiles + nchunk - 1) / nchunk;  // trailing chunks may be empty (they return at once)
     const size_t lds = (size_t)2 * kGemmTileBytes;
@@ -457,7 +511,7 @@ int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, b
                          d.pdB, ws.vposed, N, per, Mp);
     return 0;
   }
-  if (d.Kp != 208 && transposed && d.kc32 > 0 && gemm_bf16x3()) {
+  if (d.Kp != 208 && transposed && d.kc32 > 0 && gemm_bf16x3() && d.gemm_exclusive) {
     // tiled split-bf16 GEMM (SMPL-X): the feature images go to ws.vposed, which the batch-major path does not use
     const int mt = (Mp + 255) / 256, nt128 = N / 128;
     uint16_t* aimg = reinterpret_cast<uint16_t*>(ws.vposed);
@@ -485,7 +539,7 @@ int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, b
     {
       // SMPLFIT_GEMM_LDS_KB: pad the workgroup's LDS request (84 = one GEMM workgroup per CU, which leaves
       // LDS and registers for two batch-major workgroups of another chunk beside it)
-      static const int pad_kb = [] { const char* e = getenv("SMPLFIT_GEMM_LDS_KB"); return e ? atoi(e) : 0; }();
+      const int pad_kb = tune().gemm_lds_kb;
       if (pad_kb > 0) {
         lds = std::max(lds, (size_t)pad_kb * 1024);
         static std::once_flag once[16];
@@ -545,7 +599,19 @@ struct FitOptions {
   int scale_mode = 0;                 // 1 scale_target, 2 scale_fit: the last solve has a scale unknown
   float scale_reg = 0.f;
   float* scale_out = nullptr;         // (B) scale_corr
+  // fused conversion (smplfit_convert_f32): the targets are produced on the device — forward of the input model on
+  // the batch-major kernels, topology transfer straight into this fit's target stream — instead of being read
+  // from target_vertices
+  const struct ConvertSource* source = nullptr;
 };
+
+struct ConvertSource {
+  const smplfit_convert_plan* plan;
+  const float *pose, *betas, *trans;  // this chunk's rows of the input parameters; betas (B, nb) / trans may be null
+  int nb;
+  Workspace wsi;  // forward-only workspace slice of the input model (carve(..., fwd_only))
+};
+int launch_convert_source(const ConvertSource& src, const DevModel& d_out, const Workspace& ws, int B, hipStream_t st);
 
 // The solve of one shape pass on the sums already in the workspace: the plain per-instance solve, the
 // scaled solve (one more unknown; extra vertex sums first) or the shared solve (assemble, sum over the
@@ -608,11 +674,16 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   // joints (bodyfitter.py:1018-1028)
   const bool eff_v = joints ? (vw && jw) : (vw != nullptr);
   const bool eff_j = joints && vw && jw;
-  const bool bm = bm_applies(d) && !vw && !o.rotations_only && !o.scale_mode;
+  const bool bm = bm_applies(h) && !vw && !o.rotations_only && !o.scale_mode;
+  if (o.source && !bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "fused conversion: the batch-major path does not apply");
   // a warm-started fit evaluates its first part sums against the posed model with the wave-per-instance
   // kernel, which reads the per-instance sorted copy ws.tvs: that copy is produced as well then
   if (!bm || o.init_pose || o.init_betas) launch_center_sort(d, tv, tj, vw, ws, B, st);
-  if (bm) launch_layout_bm(d, tv, tj, ws, B, st);
+  if (bm && o.source) {
+    if (int rc = launch_convert_source(*o.source, d, ws, B, st)) return rc;
+  } else if (bm) {
+    launch_layout_bm(d, tv, tj, ws, B, st);
+  }
   const float* tj_rot = ws.tjc;
   if (!joints) {  // regressed target joints from the centred vertices (bodyfitter.py:1342-1344)
     if (bm)
@@ -820,6 +891,43 @@ int run_fit_known_shape(const smplfit_handle* h, const float* betas, int nb, con
   return post_launch_check();
 }
 
+// The target stream of a fused conversion (smplfit_convert_f32), per chunk:
+//   forward of the INPUT model on the batch-major kernels (k_forward_joint, transposed GEMM, joint-row transpose,
+//   forward-only LBS pass: the posed vertices stay in the input model's instance-innermost buffer),
+//   k_transfer_bm into the OUTPUT model's target stream + slab sums, then the tail of launch_layout_bm.
+int launch_convert_source(const ConvertSource& src, const DevModel& d, const Workspace& ws, int B, hipStream_t st) {
+  const smplfit_convert_plan& pl = *src.plan;
+  const DevModel& di = pl.in->d;
+  const Workspace& wi = src.wsi;
+  const int Mp = (int)align_up((size_t)B, 128);
+  hipLaunchKernelGGL(k_fill_shape, dim3((B + 255) / 256), dim3(256), 0, st, wi, B, di.S, di.jt.n_kid, src.betas,
+                     src.betas ? std::min(src.nb, di.S - di.jt.n_kid - di.jt.n_pad) : 0, (const float*)nullptr, src.trans);
+  ForwardArgs fa{};
+  fa.pose = src.pose;
+  fa.betas = wi.beta;  // (B,S) rows, zero beyond the given betas
+  fa.nb = di.S;
+  fa.joints = wi.rjoints;
+  hipLaunchKernelGGL(k_forward_joint, dim3(B), dim3(64), joint_lds(di), st, di, fa, wi);
+  if (int rc = launch_gemm(di, wi, B, st, true)) return rc;
+  launch_jd_transpose(di, wi, B, st);
+  {
+    const size_t lds = (size_t)kGQ * 12 * 64 * 4;
+    const dim3 grid = di.lpt ? dim3(Mp / 64, di.ngroups) : dim3(di.ngroups, Mp / 64);
+    if (di.S == 11)
+      hipLaunchKernelGGL((k_lbs_partsum_bm<11, 4, true, true>), grid, dim3(64 * kBW), lds, st, di, wi, B, Mp);
+    else
+      hipLaunchKernelGGL((k_lbs_partsum_bm<10, 4, true, true>), grid, dim3(64 * kBW), lds, st, di, wi, B, Mp);
+  }
+  TransferTabs tt{pl.d_oslot, pl.d_start, pl.d_islot, pl.d_w, d.V};
+  hipLaunchKernelGGL(k_transfer_bm, dim3(pl.nslab, Mp / 64), dim3(256), 0, st, tt, wi.vpT, di.Vp, ws.tT, d.Vp, ws.resP, Mp);
+  hipLaunchKernelGGL(k_mean_finish, dim3(Mp / 64), dim3(64 * kMeanWaves), 0, st, d, (const float*)nullptr, ws.resP, ws, B, Mp,
+                     pl.nslab);
+  hipLaunchKernelGGL(k_template_partsum_bm, d.lpt ? dim3(Mp / 64, d.ngroups_used) : dim3(d.ngroups_used, Mp / 64),
+                     dim3(64 * kBW), 0, st, d, ws, B, Mp);
+  hipLaunchKernelGGL(k_psum_combine, dim3((B + 255) / 256, d.J), dim3(256), 0, st, d, ws, B, Mp);
+  return 0;
+}
+
 template <typename T>
 int upload(smplfit_handle* h, const std::vector<T>& src, const T** dst) {
   void* p = nullptr;
@@ -836,12 +944,7 @@ int upload(smplfit_handle* h, const std::vector<T>& src, const T** dst) {
 // chunk overlaps the VALU / HBM-bound vertex passes of the others (measured +5 % at B = 4096).
 // Chunk sizes are multiples of 128 (the GEMM's instance tile).
 int chunk_plan(int batch, int* sizes) {
-  static const int want = [] {
-    const char* e = getenv("SMPLFIT_CHUNKS");
-    int v = e ? atoi(e) : 2;  // measured at B = 4096 (batch-major kernels, r01_h): 1 chunk 1.30 M fits/s, 2: 1.43 M, 3: 1.41 M, 4: 1.37 M
-    return v < 1 ? 1 : (v > kMaxChunks ? kMaxChunks : v);
-  }();
-  int n = want;
+  int n = std::min(tune().chunks, kMaxChunks);  // default 2; measured at B = 4096: 1 chunk 1.73, 2: 1.79, 3: 1.75, 4: 1.74 M fits/s
   while (n > 1 && batch < n * 512) --n;  // keep every chunk >= 512 instances
   const int per = ((batch + n - 1) / n + 127) / 128 * 128;
   int left = batch, k = 0;
@@ -853,13 +956,134 @@ int chunk_plan(int batch, int* sizes) {
   return k;
 }
 
-size_t chunked_workspace_bytes(const sf::HostTables& t, int batch) {
+// `tin`: the input model of a fused conversion — every chunk's slice is followed by that model's forward-only slice
+size_t chunked_workspace_bytes(const sf::HostTables& t, int batch, const sf::HostTables* tin) {
   int sizes[kMaxChunks];
   const int n = chunk_plan(batch, sizes);
   size_t total = 0;
-  for (int i = 0; i < n; ++i) total += carve(t, sizes[i], nullptr, nullptr);
-  return std::max(total, carve(t, batch, nullptr, nullptr));
+  for (int i = 0; i < n; ++i)
+    total += carve(t, sizes[i], nullptr, nullptr) + (tin ? carve(*tin, sizes[i], nullptr, nullptr, true) : 0);
+  return std::max(total, carve(t, batch, nullptr, nullptr) + (tin ? carve(*tin, batch, nullptr, nullptr, true) : 0));
 }
+
+// the input side of a fused conversion, whole batch (fit_impl cuts it into the chunks' ConvertSource)
+struct ConvertJob {
+  const smplfit_convert_plan* plan;
+  const float *pose, *betas, *trans;
+  int nb;
+};
+int fit_impl(const smplfit_handle* h, const smplfit_fit_args* args, const ConvertJob* job);
+
+int fit_impl(const smplfit_handle* h, const smplfit_fit_args* args, const ConvertJob* job) {
+  const float *target_vertices = args->target_vertices, *target_joints = args->target_joints,
+              *vertex_weights = args->vertex_weights, *joint_weights = args->joint_weights,
+              *initial_pose_rotvecs = args->initial_pose_rotvecs,
+              *initial_shape_betas = args->initial_shape_betas, *initial_kid_factor = args->initial_kid_factor;
+  const int batch = args->batch, num_iter = args->num_iter, final_adjust_rots = args->final_adjust_rots,
+            num_initial_betas = args->num_initial_betas;
+  const float beta_regularizer = args->beta_regularizer, beta_regularizer2 = args->beta_regularizer2,
+              kid_regularizer = args->kid_regularizer;
+  float *pose_rotvecs = args->pose_rotvecs, *shape_betas = args->shape_betas, *trans = args->trans,
+        *kid_factor = args->kid_factor, *orientations = args->orientations,
+        *relative_orientations = args->relative_orientations;
+  void *workspace = args->workspace, *hip_stream = args->hip_stream;
+  const size_t workspace_bytes = args->workspace_bytes;
+  int rc = check_common(h, batch, workspace, job ? (size_t)-1 : workspace_bytes);
+  if (rc) return rc;
+  if (job && workspace_bytes < chunked_workspace_bytes(h->t, batch, &job->plan->in->t))
+    return fail(SMPLFIT_ERR_WORKSPACE, "workspace too small (see smplfit_convert_workspace_bytes)");
+  if ((!target_vertices && !job) || !pose_rotvecs || !shape_betas || !trans)
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_f32: null input/output pointer");
+  if (num_iter < 1) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_f32: num_iter must be >= 1");
+  if (initial_kid_factor && !h->t.n_kid)
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_warm_f32: initial_kid_factor given to a handle without kid");
+  if (initial_shape_betas && (num_initial_betas < 0 || num_initial_betas > h->t.num_betas()))
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_warm_f32: num_initial_betas must lie in [0, the model's betas]; slice first");
+  const int inb = initial_shape_betas ? num_initial_betas : 0;
+  FitOptions o{num_iter, beta_regularizer, beta_regularizer2, kid_regularizer,
+               final_adjust_rots ? 1 : 0, 0};
+  o.share_beta = args->share_beta ? 1 : 0;
+  if (args->scale_mode < 0 || args->scale_mode > 2)
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_ex_f32: scale_mode must be 0, 1 (scale_target) or 2 (scale_fit)");
+  if (args->scale_mode && !args->scale_corr)
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_ex_f32: a scale option needs the scale_corr output");
+  if (args->share_allreduce && !o.share_beta)
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_ex_f32: share_allreduce without share_beta");
+  o.share_allreduce = args->share_allreduce;
+  o.share_user = args->share_user;
+  o.scale_mode = args->scale_mode;
+  o.scale_reg = args->scale_regularizer;
+  hipStream_t st = (hipStream_t)hip_stream;
+  int sizes[kMaxChunks];
+  // share_beta couples all instances in every shape solve: one chunk
+  const int nchunk = (h->have_streams && !o.share_beta) ? chunk_plan(batch, sizes) : 1;
+  const int J = h->t.J, V = h->t.V, Sb = h->t.num_betas();
+  const int Jin = job ? job->plan->in->t.J : 0;
+  auto chunk_bytes = [&](int nb) {
+    return carve(h->t, nb, nullptr, nullptr) + (job ? carve(job->plan->in->t, nb, nullptr, nullptr, true) : 0);
+  };
+  auto run_chunk = [&](int b0, int nb, char* wsbase, hipStream_t cs) -> int {
+    Workspace ws;
+    const size_t own = carve(h->t, nb, wsbase, &ws);
+    FitOptions oc = o;
+    ConvertSource src{};
+    if (job) {
+      src.plan = job->plan;
+      src.pose = job->pose + (size_t)b0 * Jin * 3;
+      src.betas = job->betas ? job->betas + (size_t)b0 * job->nb : nullptr;
+      src.trans = job->trans ? job->trans + (size_t)b0 * 3 : nullptr;
+      src.nb = job->nb;
+      carve(job->plan->in->t, nb, wsbase + own, &src.wsi, true);
+      oc.source = &src;
+    }
+    oc.init_pose = initial_pose_rotvecs ? initial_pose_rotvecs + (size_t)b0 * J * 3 : nullptr;
+    oc.init_betas = initial_shape_betas ? initial_shape_betas + (size_t)b0 * inb : nullptr;
+    oc.init_nb = inb;
+    oc.init_kid = initial_kid_factor ? initial_kid_factor + b0 : nullptr;
+    oc.scale_out = args->scale_corr ? args->scale_corr + b0 : nullptr;
+    return run_fit(h, target_vertices ? target_vertices + (size_t)b0 * V * 3 : nullptr,
+                   target_joints ? target_joints + (size_t)b0 * J * 3 : nullptr,
+                   vertex_weights ? vertex_weights + (size_t)b0 * V : nullptr,
+                   joint_weights ? joint_weights + (size_t)b0 * J : nullptr, nb, oc,
+                   pose_rotvecs + (size_t)b0 * J * 3, shape_betas + (size_t)b0 * Sb,
+                   trans + (size_t)b0 * 3, kid_factor ? kid_factor + b0 : nullptr,
+                   orientations ? orientations + (size_t)b0 * J * 9 : nullptr,
+                   relative_orientations ? relative_orientations + (size_t)b0 * J * 9 : nullptr, ws, cs);
+  };
+  if (nchunk <= 1) return run_chunk(0, batch, (char*)workspace, st);
+  // fork: every chunk is an independent fit with its own workspace slice; chunk 0 stays on the
+  // caller's stream, the others go to the handle's side streams and are joined back by events
+  // (stream-ordered with respect to the caller, hipGraph-capturable).  The handle's streams and
+  // events are shared state: concurrent fit calls on one handle serialise their ENQUEUE here.
+  std::lock_guard<std::mutex> lock(h->mu);
+  SF_HIP_TRY(hipEventRecord(h->ev_fork, st));
+  char* wsp = (char*)workspace;
+  int b0 = 0, first_error = 0;
+  std::string first_msg;
+  for (int c = 0; c < nchunk; ++c) {
+    hipStream_t cs = c == 0 ? st : h->side[c - 1];
+    // a failed fork is an error like any other: the chunks forked before it are still joined below
+    hipError_t fe = c > 0 ? hipStreamWaitEvent(cs, h->ev_fork, 0) : hipSuccess;
+    rc = fe != hipSuccess ? fail(SMPLFIT_ERR_HIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(fe))
+                          : run_chunk(b0, sizes[c], wsp, cs);
+    if (rc && !first_error) {
+      first_error = rc;
+      first_msg = g_last_error;
+    }
+    // a chunk that was forked is always joined back, also after an error: an unjoined fork would
+    // invalidate a stream capture and leave work in flight that the caller's stream does not wait for
+    if (c > 0 && fe == hipSuccess) {
+      (void)hipEventRecord(h->ev_join[c - 1], cs);
+      (void)hipStreamWaitEvent(st, h->ev_join[c - 1], 0);
+    }
+    if (first_error) break;
+    wsp += chunk_bytes(sizes[c]);
+    b0 += sizes[c];
+  }
+  if (first_error) return fail(first_error, first_msg);
+  return SMPLFIT_OK;
+}
+
 
 }  // namespace
 
@@ -892,7 +1116,10 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
     *out = h;
     return SMPLFIT_OK;
   }
-  sf::build_tiled_gemm_images(h->t);  // 94 MB for SMPL-X: device handles only
+  // stage images of the tiled split-bf16 GEMM (94 MB for SMPL-X): only for a model whose fits can take the
+  // batch-major path (the only launches that read them; the structural part of bm_applies)
+  if (h->t.KW == 4 && (h->t.S == 10 || h->t.S == 11) && h->t.wsum_dev <= 1e-5f)
+    sf::build_tiled_gemm_images(h->t);
   const sf::HostTables& t = h->t;
   DevModel& d = h->d;
   d.V = t.V; d.J = t.J; d.S = t.S; d.P = t.P; d.Vp = t.Vp; d.Kp = t.Kp; d.KW = t.KW;
@@ -933,6 +1160,17 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
   up(t.pdB, &d.pdB);
   up(t.pdB2, &d.pdB2);
   d.kc32 = t.kc32;
+  {
+    int regs = 1 << 20;
+    for (const void* fn : {reinterpret_cast<const void*>(&k_posedirs_gemm_bf16x3<true>),
+                           reinterpret_cast<const void*>(&k_posedirs_gemm_bf16x3<false>),
+                           reinterpret_cast<const void*>(&k_posedirs_gemm_bf16x3_tiled)}) {
+      hipFuncAttributes fa{};
+      regs = std::min(regs, hipFuncGetAttributes(&fa, fn) == hipSuccess ? fa.numRegs : 0);
+    }
+    h->gemm_vgprs = regs;
+    d.gemm_exclusive = regs >= 256 ? 1 : 0;
+  }
   std::vector<uint16_t>().swap(h->t.pdB2);  // the host copy of the stage images is not needed any more
   up(t.cpackA, &d.cpackA);
   up(t.cpackB, &d.cpackB);
@@ -975,8 +1213,7 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
         if (g < d.ngroups_used) ou.push_back(g);
       up(oa, &d.gorder_all);
       up(ou, &d.gorder_used);
-      const char* e = std::getenv("SMPLFIT_LPT");
-      d.lpt = e ? std::atoi(e) : 1;
+      d.lpt = tune().lpt;
     }
     std::vector<int32_t> mb_start(t.J + 1, 0), mb_row;
     for (int j = 0; j < t.J; ++j) {
@@ -1068,6 +1305,7 @@ int smplfit_get_info(const smplfit_handle* h, smplfit_info* info) {
   info->num_fk_levels = t.num_levels();
   info->adj_last_level = t.adj_last_level;
   info->has_device = h->has_device ? 1 : 0;
+  info->gemm_vgprs = h->gemm_vgprs;
   return SMPLFIT_OK;
 }
 
@@ -1153,95 +1391,7 @@ int smplfit_fit_warm_f32(const smplfit_handle* h, const float* target_vertices,
 
 int smplfit_fit_ex_f32(const smplfit_handle* h, const smplfit_fit_args* args) {
   if (!args) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_ex_f32: null arguments");
-  const float *target_vertices = args->target_vertices, *target_joints = args->target_joints,
-              *vertex_weights = args->vertex_weights, *joint_weights = args->joint_weights,
-              *initial_pose_rotvecs = args->initial_pose_rotvecs,
-              *initial_shape_betas = args->initial_shape_betas, *initial_kid_factor = args->initial_kid_factor;
-  const int batch = args->batch, num_iter = args->num_iter, final_adjust_rots = args->final_adjust_rots,
-            num_initial_betas = args->num_initial_betas;
-  const float beta_regularizer = args->beta_regularizer, beta_regularizer2 = args->beta_regularizer2,
-              kid_regularizer = args->kid_regularizer;
-  float *pose_rotvecs = args->pose_rotvecs, *shape_betas = args->shape_betas, *trans = args->trans,
-        *kid_factor = args->kid_factor, *orientations = args->orientations,
-        *relative_orientations = args->relative_orientations;
-  void *workspace = args->workspace, *hip_stream = args->hip_stream;
-  const size_t workspace_bytes = args->workspace_bytes;
-  int rc = check_common(h, batch, workspace, workspace_bytes);
-  if (rc) return rc;
-  if (!target_vertices || !pose_rotvecs || !shape_betas || !trans)
-    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_f32: null input/output pointer");
-  if (num_iter < 1) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_f32: num_iter must be >= 1");
-  if (initial_kid_factor && !h->t.n_kid)
-    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_warm_f32: initial_kid_factor given to a handle without kid");
-  if (initial_shape_betas && num_initial_betas < 0)
-    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_warm_f32: negative num_initial_betas");
-  const int inb = initial_shape_betas ? num_initial_betas : 0;
-  FitOptions o{num_iter, beta_regularizer, beta_regularizer2, kid_regularizer,
-               final_adjust_rots ? 1 : 0, 0};
-  o.share_beta = args->share_beta ? 1 : 0;
-  if (args->scale_mode < 0 || args->scale_mode > 2)
-    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_ex_f32: scale_mode must be 0, 1 (scale_target) or 2 (scale_fit)");
-  if (args->scale_mode && !args->scale_corr)
-    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_ex_f32: a scale option needs the scale_corr output");
-  if (args->share_allreduce && !o.share_beta)
-    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_fit_ex_f32: share_allreduce without share_beta");
-  o.share_allreduce = args->share_allreduce;
-  o.share_user = args->share_user;
-  o.scale_mode = args->scale_mode;
-  o.scale_reg = args->scale_regularizer;
-  hipStream_t st = (hipStream_t)hip_stream;
-  int sizes[kMaxChunks];
-  // share_beta couples all instances in every shape solve: one chunk
-  const int nchunk = (h->have_streams && !o.share_beta) ? chunk_plan(batch, sizes) : 1;
-  const int J = h->t.J, V = h->t.V, Sb = h->t.num_betas();
-  auto run_chunk = [&](int b0, int nb, char* wsbase, hipStream_t cs) -> int {
-    Workspace ws;
-    carve(h->t, nb, wsbase, &ws);
-    FitOptions oc = o;
-    oc.init_pose = initial_pose_rotvecs ? initial_pose_rotvecs + (size_t)b0 * J * 3 : nullptr;
-    oc.init_betas = initial_shape_betas ? initial_shape_betas + (size_t)b0 * inb : nullptr;
-    oc.init_nb = inb;
-    oc.init_kid = initial_kid_factor ? initial_kid_factor + b0 : nullptr;
-    oc.scale_out = args->scale_corr ? args->scale_corr + b0 : nullptr;
-    return run_fit(h, target_vertices + (size_t)b0 * V * 3,
-                   target_joints ? target_joints + (size_t)b0 * J * 3 : nullptr,
-                   vertex_weights ? vertex_weights + (size_t)b0 * V : nullptr,
-                   joint_weights ? joint_weights + (size_t)b0 * J : nullptr, nb, oc,
-                   pose_rotvecs + (size_t)b0 * J * 3, shape_betas + (size_t)b0 * Sb,
-                   trans + (size_t)b0 * 3, kid_factor ? kid_factor + b0 : nullptr,
-                   orientations ? orientations + (size_t)b0 * J * 9 : nullptr,
-                   relative_orientations ? relative_orientations + (size_t)b0 * J * 9 : nullptr, ws, cs);
-  };
-  if (nchunk <= 1) return run_chunk(0, batch, (char*)workspace, st);
-  // fork: every chunk is an independent fit with its own workspace slice; chunk 0 stays on the
-  // caller's stream, the others go to the handle's side streams and are joined back by events
-  // (stream-ordered with respect to the caller, hipGraph-capturable).  The handle's streams and
-  // events are shared state: concurrent fit calls on one handle serialise their ENQUEUE here.
-  std::lock_guard<std::mutex> lock(h->mu);
-  SF_HIP_TRY(hipEventRecord(h->ev_fork, st));
-  char* wsp = (char*)workspace;
-  int b0 = 0, first_error = 0;
-  std::string first_msg;
-  for (int c = 0; c < nchunk; ++c) {
-    hipStream_t cs = c == 0 ? st : h->side[c - 1];
-    if (c > 0) SF_HIP_TRY(hipStreamWaitEvent(cs, h->ev_fork, 0));
-    rc = run_chunk(b0, sizes[c], wsp, cs);
-    if (rc && !first_error) {
-      first_error = rc;
-      first_msg = g_last_error;
-    }
-    // a chunk that was forked is always joined back, also after an error: an unjoined fork would
-    // invalidate a stream capture and leave work in flight that the caller's stream does not wait for
-    if (c > 0) {
-      (void)hipEventRecord(h->ev_join[c - 1], cs);
-      (void)hipStreamWaitEvent(st, h->ev_join[c - 1], 0);
-    }
-    if (first_error) break;
-    wsp += carve(h->t, sizes[c], nullptr, nullptr);
-    b0 += sizes[c];
-  }
-  if (first_error) return fail(first_error, first_msg);
-  return SMPLFIT_OK;
+  return fit_impl(h, args, nullptr);
 }
 
 int smplfit_fit_known_shape_f32(const smplfit_handle* h, const float* shape_betas,
@@ -1293,18 +1443,32 @@ int smplfit_forward_f32(const smplfit_handle* h, const float* pose_rotvecs,
                         const float* trans, const float* kid_factor, int batch, float* vertices,
                         float* joints, float* orientations, void* workspace, size_t workspace_bytes,
                         void* hip_stream) {
-  int rc = check_common(h, batch, workspace, workspace_bytes);
+  smplfit_forward_args a{};
+  a.pose_rotvecs = pose_rotvecs; a.glob_rotmats = glob_rotmats; a.shape_betas = shape_betas;
+  a.num_betas_given = num_betas_given; a.trans = trans; a.kid_factor = kid_factor; a.batch = batch;
+  a.vertices = vertices; a.joints = joints; a.orientations = orientations;
+  a.workspace = workspace; a.workspace_bytes = workspace_bytes; a.hip_stream = hip_stream;
+  return smplfit_forward_ex_f32(h, &a);
+}
+
+int smplfit_forward_ex_f32(const smplfit_handle* h, const smplfit_forward_args* args) {
+  if (!args) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_forward_ex_f32: null arguments");
+  const int batch = args->batch, num_betas_given = args->num_betas_given;
+  const float *shape_betas = args->shape_betas, *trans = args->trans, *kid_factor = args->kid_factor;
+  float *vertices = args->vertices, *joints = args->joints;
+  int rc = check_common(h, batch, args->workspace, args->workspace_bytes);
   if (rc) return rc;
-  if (pose_rotvecs && glob_rotmats)
+  if ((args->pose_rotvecs != nullptr) + (args->glob_rotmats != nullptr) + (args->rel_rotmats != nullptr) > 1)
     return fail(SMPLFIT_ERR_BAD_ARG, "Only one rotation input may be provided");
   if (!joints) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_forward_f32: joints output is required");
   const DevModel& d = h->d;
-  hipStream_t st = (hipStream_t)hip_stream;
+  hipStream_t st = (hipStream_t)args->hip_stream;
   Workspace ws;
-  carve(h->t, batch, (char*)workspace, &ws);
+  carve(h->t, batch, (char*)args->workspace, &ws);
   ForwardArgs fa{};
-  fa.pose = pose_rotvecs;
-  fa.glob = glob_rotmats;
+  fa.pose = args->pose_rotvecs;
+  fa.glob = args->glob_rotmats;
+  fa.rel = args->rel_rotmats;
   fa.betas = shape_betas;
   fa.nb = shape_betas ? std::min(num_betas_given, d.S - d.jt.n_kid - d.jt.n_pad) : 0;
   if (kid_factor && !d.jt.n_kid)
@@ -1314,7 +1478,7 @@ int smplfit_forward_f32(const smplfit_handle* h, const float* pose_rotvecs,
     return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_forward_f32: more betas than the model holds; slice first");
   fa.trans = trans;
   fa.joints = joints;
-  fa.orient = orientations;
+  fa.orient = args->orientations;
   hipLaunchKernelGGL(k_forward_joint, dim3(batch), dim3(64), joint_lds(d), st, d, fa, ws);
   if (vertices) {
     launch_gemm(d, ws, batch, st);
@@ -1361,8 +1525,9 @@ int smplfit_shape_solve_ex_f32(const smplfit_handle* h, const smplfit_shape_solv
     return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_shape_solve_ex_f32: share_allreduce without share_beta");
   if (args->kid_regularizer_reference && !h->t.n_kid)
     return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_shape_solve_ex_f32: kid_regularizer_reference given to a handle without kid");
-  if (args->beta_regularizer_reference && args->num_reference_betas < 0)
-    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_shape_solve_ex_f32: negative num_reference_betas");
+  if (args->beta_regularizer_reference && (args->num_reference_betas < 0 || args->num_reference_betas > h->t.num_betas()))
+    return fail(SMPLFIT_ERR_BAD_ARG,
+                "smplfit_shape_solve_ex_f32: num_reference_betas must lie in [0, the model's betas]; slice first");
   const DevModel& d = h->d;
   const float *vertex_weights = args->vertex_weights, *joint_weights = args->joint_weights;
   hipStream_t st = (hipStream_t)args->hip_stream;
@@ -1423,6 +1588,170 @@ int smplfit_shape_solve_ex_f32(const smplfit_handle* h, const smplfit_shape_solv
   return post_launch_check();
 }
 
+// ---- topology transfer + fused conversion ---------------------------------------------------------
+int smplfit_transfer_create(int32_t num_vertices_in, int32_t num_vertices_out, const int32_t* indptr,
+                            const int32_t* indices, const float* values, int flags, smplfit_transfer** out) {
+  if (!out || !indptr || num_vertices_in <= 0 || num_vertices_out <= 0)
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_transfer_create: null argument / empty matrix");
+  *out = nullptr;
+  if (indptr[0] != 0) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_transfer_create: indptr[0] must be 0");
+  for (int r = 0; r < num_vertices_out; ++r)
+    if (indptr[r + 1] < indptr[r]) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_transfer_create: indptr must not decrease");
+  const int nnz = indptr[num_vertices_out];
+  if (nnz > 0 && (!indices || !values)) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_transfer_create: null indices / values");
+  for (int e = 0; e < nnz; ++e)
+    if (indices[e] < 0 || indices[e] >= num_vertices_in)
+      return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_transfer_create: column index outside the input vertices");
+  auto* t = new smplfit_transfer();
+  t->v_in = num_vertices_in;
+  t->v_out = num_vertices_out;
+  t->indptr.assign(indptr, indptr + num_vertices_out + 1);
+  t->indices.assign(indices, indices + nnz);
+  t->values.assign(values, values + nnz);
+  if (!(flags & SMPLFIT_CREATE_HOST_ONLY)) {
+    auto up = [&](const void* src, size_t bytes, void** dst) {
+      if (hipMalloc(dst, std::max<size_t>(bytes, 16)) != hipSuccess) return false;
+      return bytes == 0 || hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    };
+    if (!up(t->indptr.data(), t->indptr.size() * 4, (void**)&t->d_indptr) ||
+        !up(t->indices.data(), t->indices.size() * 4, (void**)&t->d_indices) ||
+        !up(t->values.data(), t->values.size() * 4, (void**)&t->d_values)) {
+      smplfit_transfer_destroy(t);
+      return fail(SMPLFIT_ERR_HIP, "smplfit_transfer_create: device upload failed");
+    }
+  }
+  *out = t;
+  return SMPLFIT_OK;
+}
+
+void smplfit_transfer_destroy(smplfit_transfer* t) {
+  if (!t) return;
+  if (t->d_indptr) (void)hipFree(t->d_indptr);
+  if (t->d_indices) (void)hipFree(t->d_indices);
+  if (t->d_values) (void)hipFree(t->d_values);
+  delete t;
+}
+
+int smplfit_transfer_f32(const smplfit_transfer* t, const float* in_vertices, int batch, float* out_vertices,
+                         void* hip_stream) {
+  if (!t || !in_vertices || !out_vertices || batch < 0)
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_transfer_f32: null pointer / negative batch");
+  if (!t->d_indptr) return fail(SMPLFIT_ERR_HIP, "smplfit_transfer_f32: the matrix was created host-only (no device)");
+  if (batch == 0) return SMPLFIT_OK;
+  hipStream_t st = (hipStream_t)hip_stream;
+  const size_t lds = (size_t)t->v_in * 12;
+  if (lds <= 160 * 1024) {
+    static std::once_flag once[16];
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    std::call_once(once[dev_id & 15], [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_transfer_rows<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    hipLaunchKernelGGL(k_transfer_rows<true>, dim3(batch), dim3(1024), lds, st, in_vertices, out_vertices, t->d_indptr,
+                       t->d_indices, t->d_values, t->v_in, t->v_out);
+  } else {
+    hipLaunchKernelGGL(k_transfer_rows<false>, dim3(batch), dim3(1024), 0, st, in_vertices, out_vertices, t->d_indptr,
+                       t->d_indices, t->d_values, t->v_in, t->v_out);
+  }
+  return post_launch_check();
+}
+
+int smplfit_convert_plan_create(const smplfit_handle* in, const smplfit_handle* out, const smplfit_transfer* transfer,
+                                smplfit_convert_plan** plan) {
+  if (!in || !out || !plan) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_convert_plan_create: null argument");
+  *plan = nullptr;
+  if (!in->has_device || !out->has_device)
+    return fail(SMPLFIT_ERR_HIP, "smplfit_convert_plan_create: both handles need a device");
+  if (transfer ? (transfer->v_in != in->t.V || transfer->v_out != out->t.V) : (in->t.V != out->t.V))
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_convert_plan_create: vertex counts of the models and the matrix disagree");
+  if (!bm_applies(in) || !bm_applies(out) || !out->t.has_regressor)
+    return fail(SMPLFIT_ERR_UNSUPPORTED,
+                "smplfit_convert_plan_create: the fused conversion needs the batch-major kernels on both models "
+                "(<= 4 skinning weights per vertex, 10 betas, >= 1024 vertices) and the output model's joint "
+                "regressor; use forward + smplfit_transfer_f32 + fit");
+  const int Vo = out->t.V;
+  std::vector<int32_t> inv_in(in->t.V, 0), oslot(Vo, 0), start(Vo + 1, 0), islot;
+  std::vector<float> w;
+  for (int i = 0; i < in->t.Vp; ++i)
+    if (in->t.perm[i] >= 0) inv_in[in->t.perm[i]] = i;
+  for (int i = 0; i < out->t.Vp; ++i)
+    if (out->t.perm[i] >= 0) oslot[out->t.perm[i]] = i;
+  for (int r = 0; r < Vo; ++r) {
+    if (transfer) {
+      for (int e = transfer->indptr[r]; e < transfer->indptr[r + 1]; ++e) {
+        islot.push_back(inv_in[transfer->indices[e]]);
+        w.push_back(transfer->values[e]);
+      }
+    } else {  // same topology: the identity
+      islot.push_back(inv_in[r]);
+      w.push_back(1.f);
+    }
+    start[r + 1] = (int32_t)islot.size();
+  }
+  auto* p = new smplfit_convert_plan();
+  p->in = in;
+  p->out = out;
+  p->nslab = (Vo + kSlabV - 1) / kSlabV;
+  auto up = [&](const void* src, size_t bytes, void** dst) {
+    if (hipMalloc(dst, std::max<size_t>(bytes, 16)) != hipSuccess) return false;
+    return bytes == 0 || hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+  };
+  if (!up(oslot.data(), oslot.size() * 4, (void**)&p->d_oslot) || !up(start.data(), start.size() * 4, (void**)&p->d_start) ||
+      !up(islot.data(), islot.size() * 4, (void**)&p->d_islot) || !up(w.data(), w.size() * 4, (void**)&p->d_w)) {
+    smplfit_convert_plan_destroy(p);
+    return fail(SMPLFIT_ERR_HIP, "smplfit_convert_plan_create: device upload failed");
+  }
+  *plan = p;
+  return SMPLFIT_OK;
+}
+
+void smplfit_convert_plan_destroy(smplfit_convert_plan* p) {
+  if (!p) return;
+  for (void* q : {(void*)p->d_oslot, (void*)p->d_start, (void*)p->d_islot, (void*)p->d_w})
+    if (q) (void)hipFree(q);
+  delete p;
+}
+
+size_t smplfit_convert_workspace_bytes(const smplfit_convert_plan* p, int batch) {
+  if (!p || batch <= 0) return 0;
+  return chunked_workspace_bytes(p->out->t, batch, &p->in->t);
+}
+
+int smplfit_convert_f32(const smplfit_convert_plan* p, const smplfit_convert_args* a) {
+  if (!p || !a) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_convert_f32: null argument");
+  if (!a->pose_rotvecs) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_convert_f32: pose_rotvecs is required");
+  if (a->shape_betas && (a->num_betas_given < 0 || a->num_betas_given > p->in->t.num_betas()))
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_convert_f32: more betas than the input model holds; slice first");
+  // the plan was made while the batch-major path applied; a later smplfit_reload_options may have switched it off
+  if (!bm_applies(p->in) || !bm_applies(p->out))
+    return fail(SMPLFIT_ERR_UNSUPPORTED, "smplfit_convert_f32: the batch-major path is switched off");
+  smplfit_fit_args f{};
+  f.batch = a->batch;
+  f.num_iter = a->num_iter;
+  f.beta_regularizer = a->beta_regularizer;
+  f.beta_regularizer2 = a->beta_regularizer2;
+  f.kid_regularizer = a->kid_regularizer;
+  f.final_adjust_rots = a->final_adjust_rots;
+  f.pose_rotvecs = a->out_pose_rotvecs;
+  f.shape_betas = a->out_shape_betas;
+  f.trans = a->out_trans;
+  f.kid_factor = a->out_kid_factor;
+  f.orientations = a->out_orientations;
+  f.relative_orientations = a->out_relative_orientations;
+  f.workspace = a->workspace;
+  f.workspace_bytes = a->workspace_bytes;
+  f.hip_stream = a->hip_stream;
+  ConvertJob job{p, a->pose_rotvecs, a->shape_betas, a->trans, a->shape_betas ? a->num_betas_given : 0};
+  return fit_impl(p->out, &f, &job);
+}
+
+int smplfit_reload_options(void) {
+  (void)tune();  // make sure the first-use load has happened, then replace it
+  load_tuning();
+  return SMPLFIT_OK;
+}
+
 int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, int reps,
                             void* workspace, size_t workspace_bytes, void* hip_stream,
                             float* avg_ms) {
@@ -1436,7 +1765,7 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
   hipEvent_t e0, e1;
   SF_HIP_TRY(hipEventCreate(&e0));
   SF_HIP_TRY(hipEventCreate(&e1));
-  const bool bm = bm_applies(d);  // time the kernels the default fit runs
+  const bool bm = bm_applies(h);  // time the kernels the default fit runs
   const int Mp = (int)align_up((size_t)batch, 128);
   auto once = [&]() -> int {
     switch (kernel_id) {

@@ -171,14 +171,8 @@ class BodyModel(nn.Module):
                 res['vertices'] = torch.empty((0, V, 3), device=device)
             return res
         prep = lambda t: None if t is None else t.to(device=device, dtype=torch.float32).contiguous()  # noqa: E731
-        if rel_rotmats is not None:
-            # relative -> global rotations: FK of rotation matrices (host-side glue, J small matmuls;
-            # pt/bodymodel.py:230-234), then the glob_rotmats entry of the kernel
-            rel = prep(rel_rotmats)
-            glob = [rel[:, 0]]
-            for i in range(1, J):
-                glob.append(glob[self.kintree_parents[i]] @ rel[:, i])
-            glob_rotmats = torch.stack(glob, dim=1)
+        # rel_rotmats: the kinematic chain of pt/bodymodel.py:230-234 runs inside the joint kernel
+        rel = prep(rel_rotmats.reshape(batch, J, 3, 3)) if rel_rotmats is not None else None
         pose = prep(pose_rotvecs.reshape(batch, J * 3)) if pose_rotvecs is not None else None
         glob = prep(glob_rotmats)
         betas = prep(shape_betas)
@@ -202,9 +196,13 @@ class BodyModel(nn.Module):
         verts = torch.empty((batch, V, 3), dtype=torch.float32, device=device) if return_vertices else None
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
-            _lib.check(_lib.load().smplfit_forward_f32(
-                h.ptr, _ptr(pose), _ptr(glob), _ptr(betas), nb, _ptr(tr), _ptr(kid), batch, _ptr(verts),
-                _ptr(joints), _ptr(orient), _ptr(ws), ws.numel(), C.c_void_p(stream)))
+            p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+            args = _lib.ForwardArgs(
+                pose_rotvecs=p(pose), glob_rotmats=p(glob), rel_rotmats=p(rel), shape_betas=p(betas),
+                num_betas_given=nb, trans=p(tr), kid_factor=p(kid), batch=batch, vertices=p(verts),
+                joints=p(joints), orientations=p(orient), workspace=ws.data_ptr(), workspace_bytes=ws.numel(),
+                hip_stream=stream)
+            _lib.check(_lib.load().smplfit_forward_ex_f32(h.ptr, C.byref(args)))
         res = dict(joints=joints, orientations=orient)
         if return_vertices:
             res['vertices'] = verts

@@ -314,7 +314,7 @@ def _nearest3(src_pts, query_pts):
     return idx.astype(np.int64), w.astype(np.float32)
 
 
-def write_transfer_files(data_root, seed=0):
+def write_transfer_files(data_root, seed=0, smplx_kind='smplx'):
     """Synthetic stand-ins, in the official file layouts, for the topology-transfer and mirror files
     ``BodyConverter`` / ``BodyFlipper`` read under ``$DATA_ROOT/body_models`` (reference
     common.py:425-429, pt/bodyflipper.py:136-169):
@@ -327,7 +327,7 @@ def write_transfer_files(data_root, seed=0):
     import scipy.sparse as sp
 
     smpl = make_model_arrays('smpl', seed)['v_template'].astype(np.float64)
-    smplx = make_model_arrays('smplx', seed)['v_template'].astype(np.float64)
+    smplx = make_model_arrays(smplx_kind, seed)['v_template'].astype(np.float64)  # 'smplx' or its fat-part variant
     d = osp.join(data_root, 'body_models')
     os.makedirs(osp.join(d, 'smplx'), exist_ok=True)
 

@@ -44,3 +44,30 @@ def data_root():
     from smplfitter_amd import synth
 
     return synth.write_transfer_files(os.getenv('SMPLFIT_SYNTH_DATA', '/tmp/smplfit_synth_data_seed0'))
+
+
+@pytest.fixture(scope='session')
+def data_root_fat():
+    """The same for SMPL <-> the fat-part SMPL-X variant (the cross-topology BodyConverter fixture)."""
+    from smplfitter_amd import synth
+
+    return synth.write_transfer_files(os.getenv('SMPLFIT_SYNTH_DATA_FAT', '/tmp/smplfit_synth_data_fat_seed0'),
+                                      smplx_kind='smplx_fat')
+
+
+@pytest.fixture
+def smplfit_env(monkeypatch):
+    """Set / clear a SMPLFIT_* tuning variable for one test: the library reads them once, so every change is followed
+    by smplfit_reload_options(); restored (and re-read) afterwards."""
+    from smplfitter_amd import _lib
+
+    def set_var(name, value):
+        if value is None:
+            monkeypatch.delenv(name, raising=False)
+        else:
+            monkeypatch.setenv(name, value)
+        _lib.reload_options()
+
+    yield set_var
+    monkeypatch.undo()
+    _lib.reload_options()

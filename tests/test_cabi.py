@@ -152,3 +152,44 @@ def test_model_unpickler_is_restricted(tmp_path):
     m = sp.random(5, 7, density=0.4, format='csc', dtype=np.float64, random_state=0)
     back = modelio.restricted_load(io.BytesIO(pickle.dumps({'mtx': m, 'a': np.arange(4.0)}, protocol=2)))
     assert (back['mtx'] != m).nnz == 0 and np.array_equal(back['a'], np.arange(4.0))
+
+
+def test_transfer_create_validates(lib):
+    """smplfit_transfer_create (host-only: no GPU needed) rejects malformed CSR input with the BAD_ARG status
+    (ValueError through _lib.check) and accepts empty rows."""
+    import ctypes as C
+
+    from smplfitter_amd import _lib
+
+    indptr = np.array([0, 2, 2, 3], np.int32)
+    indices = np.array([0, 4, 1], np.int32)
+    values = np.array([0.5, 0.5, 1.0], np.float32)
+    tr = _lib.Transfer(5, 3, indptr, indices, values, host_only=True)
+    assert tr.shape == (3, 5)
+    # a host-only matrix cannot compute
+    with pytest.raises(_lib.SmplfitError):
+        _lib.check(lib.smplfit_transfer_f32(tr.ptr, C.c_void_p(16), 1, C.c_void_p(16), None))
+    tr.close()
+    with pytest.raises(ValueError):  # column index outside the input vertices
+        _lib.Transfer(4, 3, indptr, indices, values, host_only=True)
+    with pytest.raises(ValueError):  # decreasing indptr
+        _lib.Transfer(5, 3, np.array([0, 2, 1, 3], np.int32), indices, values, host_only=True)
+    with pytest.raises(ValueError):  # indptr[0] != 0
+        _lib.Transfer(5, 3, np.array([1, 2, 2, 3], np.int32), indices, values, host_only=True)
+    with pytest.raises(ValueError):  # shapes that are not a CSR matrix (caught before the call)
+        _lib.Transfer(5, 3, indptr[:-1], indices, values, host_only=True)
+    out = C.c_void_p()
+    assert lib.smplfit_convert_plan_create(None, None, None, C.byref(out)) == _lib.SMPLFIT_ERR_BAD_ARG
+    assert lib.smplfit_convert_workspace_bytes(None, 8) == 0
+    assert lib.smplfit_convert_f32(None, None) == _lib.SMPLFIT_ERR_BAD_ARG
+
+
+def test_reload_options(lib, monkeypatch):
+    """The tuning variables are read once; smplfit_reload_options() picks up a change (workspace size follows the
+    chunk count only through the chunk plan, so the call itself is the observable here)."""
+    from smplfitter_amd import _lib
+
+    monkeypatch.setenv('SMPLFIT_CHUNKS', '1')
+    _lib.reload_options()
+    monkeypatch.delenv('SMPLFIT_CHUNKS')
+    _lib.reload_options()

@@ -161,7 +161,7 @@ def test_parity_statistics(name, model_root, golden, dev, capsys):
                    if 'betas' in r else ''), end='')
 
 
-def test_gemm_split_precision(model_root, golden, dev, monkeypatch):
+def test_gemm_split_precision(model_root, golden, dev, smplfit_env):
     """The posedirs contraction on the bf16 matrix cores (three-way error-free split of both fp32 operands,
     six products, fp32 accumulate: k_posedirs_gemm_bf16x3, the default) is fp32-equivalent: against the
     fp64 oracle its forward mesh is as accurate as the one computed with the fp32 MFMA (SMPLFIT_GEMM=f32),
@@ -179,10 +179,10 @@ def test_gemm_split_precision(model_root, golden, dev, monkeypatch):
         trans = rs.randn(B, 3).astype(np.float32)
         ref = om64.forward(pose, betas, trans)['vertices']
         for mode in ('bf16x3', 'f32'):
-            monkeypatch.setenv('SMPLFIT_GEMM', mode)
+            smplfit_env('SMPLFIT_GEMM', mode)
             v = m(t(pose, dev), t(betas, dev), t(trans, dev))['vertices'].cpu().numpy()
             errs[(scale, mode)] = float(np.abs(v - ref).max())
-    monkeypatch.delenv('SMPLFIT_GEMM')
+    smplfit_env('SMPLFIT_GEMM', None)
     print('\n[gemm] max |forward - fp64| (m):', {f'{k[1]}@{k[0]}': f'{v:.2e}' for k, v in errs.items()})
     for scale in (0.1, 1.0):
         assert errs[(scale, 'f32')] < 2e-6 and errs[(scale, 'bf16x3')] < 2e-6
@@ -190,16 +190,16 @@ def test_gemm_split_precision(model_root, golden, dev, monkeypatch):
     tv, tj = make_targets(m, 256, 9, dev)
     out = {}
     for mode in ('bf16x3', 'f32'):
-        monkeypatch.setenv('SMPLFIT_GEMM', mode)
+        smplfit_env('SMPLFIT_GEMM', mode)
         out[mode] = to_np(f.fit(tv, tj, num_iter=3, beta_regularizer=1.0, requested_keys=['pose_rotvecs']))
-    monkeypatch.delenv('SMPLFIT_GEMM')
+    smplfit_env('SMPLFIT_GEMM', None)
     assert np.abs(out['bf16x3']['shape_betas'] - out['f32']['shape_betas']).max() < 2e-5
     assert np.abs(out['bf16x3']['trans'] - out['f32']['trans']).max() < 2e-6
     assert util.vertex_l2(om64, out['bf16x3'], out['f32']) < 2e-5
 
 
 @pytest.mark.parametrize('B', [300, 1024])
-def test_gemm_tiled_split_smplx(B, model_root, golden, dev, monkeypatch):
+def test_gemm_tiled_split_smplx(B, model_root, golden, dev, smplfit_env):
     """SMPL-X (K = 487): the batch-major path runs the tiled split-bf16 GEMM (k_posedirs_gemm_bf16x3_tiled, feature
     images by k_split_features); whole fits agree with the fp32-MFMA GEMM (SMPLFIT_GEMM=f32) to the last digits —
     B = 300 leaves the second 256-instance tile mostly empty, 1024 runs as two chunks."""
@@ -210,9 +210,9 @@ def test_gemm_tiled_split_smplx(B, model_root, golden, dev, monkeypatch):
     tv, tj = make_targets(m, B, 5, dev)
     out = {}
     for mode in ('bf16x3', 'f32'):
-        monkeypatch.setenv('SMPLFIT_GEMM', mode)
+        smplfit_env('SMPLFIT_GEMM', mode)
         out[mode] = to_np(f.fit(tv, tj, num_iter=3, beta_regularizer=1.0, requested_keys=['pose_rotvecs']))
-    monkeypatch.delenv('SMPLFIT_GEMM')
+    smplfit_env('SMPLFIT_GEMM', None)
     assert np.isfinite(out['bf16x3']['pose_rotvecs']).all()
     assert np.abs(out['bf16x3']['shape_betas'] - out['f32']['shape_betas']).max() < 5e-5
     assert np.abs(out['bf16x3']['trans'] - out['f32']['trans']).max() < 2e-6
@@ -266,6 +266,99 @@ def test_full_size_vs_oracle_samples(B, model_root, golden, dev):
             assert torch.equal(r[k][s], r3[k]), k  # an instance's result does not depend on its batch
         fw = m(r['pose_rotvecs'], r['shape_betas'], r['trans'])
         assert (fw['vertices'] - tv).norm(dim=-1).mean().item() < 1e-2  # round trip (beta_regularizer = 1)
+
+
+@pytest.mark.parametrize('name,B', [('smplxfat', 4096), ('smpl1024', 16384)])
+def test_full_size_vs_oracle_samples_c3_c4(name, B, model_root, golden, dev):
+    """BASELINE.json configs 3 and 4 at full size, compared DIRECTLY with the fp64 oracle: the SMPL-X-shaped model
+    (10475 vertices, 55 joints; the well-conditioned fat-part variant, so that the pose gate means something) at
+    B = 4096 and the 1024-vertex SMPL subset at B = 16384 — instances sampled across the batch (both ends, the chunk
+    boundary, instance-block and GEMM-tile boundaries).  Gates as test_full_size_vs_oracle_samples."""
+    g = golden(name)
+    kind, md = util.load_md(model_root, name, g)
+    om64, of64 = util.make_oracle(md, kind, np.float64)
+    m, f = get_model(model_root, name, g, dev)
+    tv, tj = make_targets(m, B, 42, dev)
+    r = f.fit(tv, tj, num_iter=3, beta_regularizer=1.0, requested_keys=['pose_rotvecs'])
+    assert all(torch.isfinite(r[k]).all() for k in ('pose_rotvecs', 'shape_betas', 'trans'))
+    idx = _sample_rows(B)[::2] if name == 'smplxfat' else _sample_rows(B)  # the SMPL-X oracle is 4x the work
+    ti = torch.from_numpy(idx).to(dev)
+    o = {k: r[k][ti].cpu().numpy() for k in ('pose_rotvecs', 'shape_betas', 'trans')}
+    ref = of64.fit(tv[ti].cpu().numpy(), tj[ti].cpu().numpy(), num_iter=3, beta_regularizer=1.0)
+    errs = dict(vertex=util.vertex_l2(om64, o, ref), betas=float(np.abs(o['shape_betas'] - ref['shape_betas']).max()),
+                trans=float(np.abs(o['trans'] - ref['trans']).max()),
+                pose=float(np.abs(o['pose_rotvecs'] - ref['pose_rotvecs']).max()))
+    print(f'\n[full-size] {name}@{B}: ' + ' '.join(f'{k} {v:.2e}' for k, v in errs.items()))
+    assert errs['vertex'] < 1e-4 and errs['betas'] < 1e-4 and errs['trans'] < 1e-5 and errs['pose'] < 3e-4, errs
+
+
+def test_neighbour_stress(model_root, golden, dev):
+    """The split-bf16 GEMM must never share a CU with another kernel (k_posedirs_gemm_bf16x3, "exclusive CU"): beside
+    its LDS-fed bf16 MFMAs, other kernels' waves were seen to read wrong lanes.  The guard is an occupancy one (256
+    VGPRs x 8 waves), so it is stressed: 200 default two-chunk fits at B = 4096 while a SECOND handle fits on its own
+    stream from another thread and torch streams elementwise kernels on a third — every one of the 200 results must
+    be bit-identical to the first.  Also checks the kernel really allocates the whole register file."""
+    import threading
+
+    from smplfitter_amd.pt import BodyFitter, BodyModel
+
+    g = golden('smpl')
+    m, f = get_model(model_root, 'smpl', g, dev)
+    B = 4096
+    tv, tj = make_targets(m, B, 42, dev)
+    h = m._native(dev)
+    assert h.info.gemm_vgprs >= 256, h.info.gemm_vgprs  # the occupancy guard: 8 waves x 256 registers = one CU
+    ws = torch.empty(h.workspace_bytes(B), dtype=torch.uint8, device=dev)
+    kw = dict(num_iter=3, beta_regularizer=1.0, requested_keys=['pose_rotvecs'], _workspace=ws)
+    ref = f.fit(tv, tj, **kw)
+    ref = {k: ref[k].clone() for k in ('pose_rotvecs', 'shape_betas', 'trans')}
+    torch.cuda.synchronize()
+    # foreign work: another handle of the same model (its own constants, streams, workspace) + torch elementwise
+    m2 = BodyModel('smpl', 'neutral', model_root=f'{model_root}/smpl', num_betas=10, device=dev)
+    f2 = BodyFitter(m2)
+    tv2, tj2 = make_targets(m2, 2048, 7, dev)
+    stop = threading.Event()
+    errors = []
+
+    def foreign_fit():
+        try:
+            s = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(s):
+                ws2 = torch.empty(m2._native(dev).workspace_bytes(2048), dtype=torch.uint8, device=dev)
+                while not stop.is_set():
+                    f2.fit(tv2, tj2, num_iter=2, beta_regularizer=1.0, _workspace=ws2)
+                    s.synchronize()
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+
+    def foreign_elementwise():
+        try:
+            s = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(s):
+                x = torch.randn(1 << 24, device=dev)
+                while not stop.is_set():
+                    for _ in range(8):
+                        x = torch.sin(x) * 1.0001 + 0.5
+                    s.synchronize()
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=foreign_fit), threading.Thread(target=foreign_elementwise)]
+    for th in threads:
+        th.start()
+    bad = torch.zeros((), dtype=torch.int64, device=dev)
+    try:
+        for _ in range(200):
+            r = f.fit(tv, tj, **kw)
+            for k, v in ref.items():
+                bad += (r[k] != v).sum()
+        torch.cuda.synchronize()
+    finally:
+        stop.set()
+        for th in threads:
+            th.join()
+    assert not errors, errors
+    assert int(bad.item()) == 0, f'{int(bad.item())} result values differed from the first fit under foreign load'
 
 
 @pytest.mark.parametrize('launcher', ['self', 'torchrun'])

@@ -33,8 +33,8 @@ def get_model(model_root, name, g, dev):
 
     if name not in _models:
         kind = 'smplx' if name.startswith('smplx') else 'smpl'
-        kw = dict(vertex_subset=g['vertex_subset']) if 'vertex_subset' in g else {}
-        m = BodyModel(kind, 'neutral', model_root=f'{model_root}/{kind}', num_betas=10, device=dev, **kw)
+        kw = dict(vertex_subset=g['vertex_subset']) if g is not None and 'vertex_subset' in g else {}
+        m = BodyModel(kind, 'neutral', model_root=f'{model_root}/{util.model_dir(name)}', num_betas=10, device=dev, **kw)
         _models[name] = (m, BodyFitter(m))
     return _models[name]
 
@@ -62,11 +62,11 @@ def test_forward_goldens(name, model_root, golden, dev):
 
 
 @pytest.fixture(params=['batch-major', 'wave-per-instance'])
-def vertex_path(request, monkeypatch):
+def vertex_path(request, smplfit_env):
     """The default fit takes the batch-major vertex kernels where they apply (unit vertex weights, joints
     given, SMPL-sized model); SMPLFIT_BM=0 forces the wave-per-instance kernels.  Both must agree with
     the reference."""
-    monkeypatch.setenv('SMPLFIT_BM', '1' if request.param == 'batch-major' else '0')
+    smplfit_env('SMPLFIT_BM', '1' if request.param == 'batch-major' else '0')
     return request.param
 
 
@@ -323,6 +323,101 @@ def test_convert_vertices_sparse(model_root, golden, dev, tmp_path, monkeypatch)
     out = conv.convert_vertices(v).cpu().numpy()
     ref = np.einsum('ov,bvc->boc', mat.toarray(), g['target_vertices'])
     assert out.shape == (4, 10475, 3) and np.abs(out - ref).max() < 1e-5
+
+
+def test_transfer_matrix_shapes(dev):
+    """smplfit_transfer_f32 on matrices a barycentric file does not produce: empty rows, rows of 1 .. 7 entries,
+    repeated columns, an input wider than the LDS staging (gather from global memory), batch 1 and 0."""
+    import ctypes as C
+
+    import scipy.sparse as sp
+
+    from smplfitter_amd import _lib
+
+    rs = np.random.RandomState(5)
+    for vin, vout in ((300, 517), (20000, 1000)):
+        nnz_row = rs.randint(0, 8, size=vout)
+        rows = np.repeat(np.arange(vout), nnz_row)
+        cols = rs.randint(0, vin, size=rows.shape)
+        vals = rs.randn(rows.shape[0]).astype(np.float32)
+        m = sp.csr_matrix(sp.coo_matrix((vals, (rows, cols)), shape=(vout, vin)))  # duplicates summed
+        tr = _lib.Transfer(vin, vout, m.indptr, m.indices, m.data)
+        for B in (1, 3):
+            x = rs.randn(B, vin, 3).astype(np.float32)
+            xd, out = t(x, dev), torch.full((B, vout, 3), 7.0, device=dev)
+            _lib.check(_lib.load().smplfit_transfer_f32(tr.ptr, C.c_void_p(xd.data_ptr()), B, C.c_void_p(out.data_ptr()),
+                                                        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+            ref = np.stack([m @ x[b] for b in range(B)])
+            assert np.abs(out.cpu().numpy() - ref).max() < 2e-5
+        _lib.check(_lib.load().smplfit_transfer_f32(tr.ptr, C.c_void_p(xd.data_ptr()), 0, C.c_void_p(out.data_ptr()), None))
+        with pytest.raises(ValueError):
+            _lib.check(_lib.load().smplfit_transfer_f32(tr.ptr, None, 1, C.c_void_p(out.data_ptr()), None))
+
+
+@pytest.mark.parametrize('path', ['fused', 'unfused'])
+@pytest.mark.parametrize('tag', ['s2x', 'x2s'])
+def test_convert_cross_topology(tag, path, model_root, golden, dev, data_root_fat, monkeypatch, smplfit_env):
+    """BodyConverter between the SMPL and SMPL-X topologies against the reference's own outputs
+    (tests/golden/make_golden_convert.py ran pt/bodyconverter.py:22-149 on the synthetic transfer files): the
+    transferred mesh, the default branch for 1 and 3 iterations, with kid_factor, and the two known_output_*
+    branches.  'fused' = smplfit_convert_f32 (forward, transfer and fit share the instance-innermost streams);
+    'unfused' (SMPLFIT_BM=0: no plan) = smplfit_forward_f32 + smplfit_transfer_f32 + smplfit_fit_ex_f32."""
+    from smplfitter_amd.pt import BodyConverter
+
+    smplfit_env('SMPLFIT_BM', '1' if path == 'fused' else '0')
+    monkeypatch.setenv('DATA_ROOT', data_root_fat)
+    gc = golden('convert')
+    a, b = util.CONVERT_DIRS[tag]
+    assert util.csr_digest(util.load_transfer_csr(data_root_fat, tag)) == str(gc[f'{tag}.csr_sha256'])
+    mi, _ = get_model(model_root, a, None, dev)
+    mo, _ = get_model(model_root, b, None, dev)
+    _, md_out = util.load_md(model_root, b)
+    om_out = util.O.OracleModel(md_out, np.float64, 'smplx' if b.startswith('smplx') else 'smpl')
+    conv = BodyConverter(mi, mo)
+    assert (conv._plan(dev) is not None) == (path == 'fused')
+    pose, betas, trans, kid = (t(gc[f'{tag}.{k}'], dev) for k in ('pose', 'betas', 'trans', 'kid'))
+    v = conv.convert_vertices(mi(pose, betas, trans)['vertices'])
+    assert v.shape == (8, mo.num_vertices, 3)
+    assert np.abs(v.cpu().numpy()[:, ::97] - gc[f'{tag}.vertices_sub']).max() < 3e-6
+    for ni in (1, 3):
+        util.check_convert(om_out, tag, f'it{ni}', to_np(conv.convert(pose, betas, trans, num_iter=ni)), gc)
+    util.check_convert(om_out, tag, 'kid.it1', to_np(conv.convert(pose, betas, trans, kid_factor=kid, num_iter=1)), gc)
+    util.check_convert(om_out, tag, 'kshape', to_np(conv.convert(
+        pose, betas, trans, known_output_shape_betas=t(gc[f'{tag}.kshape.betas_in'], dev), num_iter=2)), gc)
+    util.check_convert(om_out, tag, 'kpose', to_np(conv.convert(
+        pose, betas, trans, known_output_pose_rotvecs=t(gc[f'{tag}.kpose.pose_in'], dev))), gc)
+
+
+def test_convert_fused_matches_unfused(model_root, golden, dev, data_root_fat, monkeypatch, smplfit_env):
+    """The fused conversion against the three separate calls on a batch that is chunked (B = 1100 -> two chunks, the
+    second partial) and on the same-topology pair: same algorithm, different kernels and summation orders."""
+    from smplfitter_amd.pt import BodyConverter
+
+    monkeypatch.setenv('DATA_ROOT', data_root_fat)
+    ms, _ = get_model(model_root, 'smpl', None, dev)
+    mx, _ = get_model(model_root, 'smplxfat', None, dev)
+    _, md = util.load_md(model_root, 'smplxfat')
+    om = {'smplxfat': util.O.OracleModel(md, np.float64, 'smplx')}
+    _, md = util.load_md(model_root, 'smpl')
+    om['smpl'] = util.O.OracleModel(md, np.float64, 'smpl')
+    rs = np.random.RandomState(21)
+    for (mi, mo, oname), B in (((ms, mx, 'smplxfat'), 1100), ((ms, ms, 'smpl'), 300), ((mx, ms, 'smpl'), 130)):
+        pose = t((rs.randn(B, 3 * mi.num_joints) * 0.1).astype(np.float32), dev)
+        betas = t((rs.randn(B, 10) * 0.5).astype(np.float32), dev)
+        trans = t(rs.randn(B, 3).astype(np.float32), dev)
+        res = {}
+        for path in ('fused', 'unfused'):
+            smplfit_env('SMPLFIT_BM', '1' if path == 'fused' else '0')
+            conv = BodyConverter(mi, mo)
+            assert (conv._plan(dev) is not None) == (path == 'fused')
+            res[path] = to_np(conv.convert(pose, betas, trans, num_iter=2))
+        n = min(B, 48)
+        idx = np.r_[0:n // 2, B - n // 2:B]  # both ends of the batch (both chunks)
+        a = {k: v[idx] for k, v in res['fused'].items()}
+        b = {k: v[idx] for k, v in res['unfused'].items()}
+        assert np.isfinite(res['fused']['pose_rotvecs']).all()
+        assert util.vertex_l2(om[oname], a, b) < 1e-4
+        assert np.abs(res['fused']['trans'] - res['unfused']['trans']).max() < 2e-5
 
 
 @pytest.mark.parametrize('name', ['smpl', 'smplx'])

@@ -298,3 +298,33 @@ def test_num_betas_goldens(nb, model_root, golden):
         of = util.O.OracleFitter(om, enable_kid=kid)
         o = of.fit(gnb[f'nb{nb}.target_vertices'], gnb[f'nb{nb}.target_joints'], **util.NB_CFG[cfg])
         util.check_nb(om64, gnb, nb, kid, cfg, o)
+
+
+@pytest.mark.parametrize('tag', ['s2x', 'x2s'])
+def test_convert_cross_topology_goldens(tag, model_root, golden, data_root_fat):
+    """BodyConverter between the two topologies (reference pt/bodyconverter.py:22-149 run on the synthetic
+    transfer files): oracle forward of the input model -> the CSR product -> oracle fit of the output model with the
+    kid unknown, against the reference's outputs (every branch of convert)."""
+    gc = golden('convert')
+    a, b = util.CONVERT_DIRS[tag]
+    csr = util.load_transfer_csr(data_root_fat, tag)
+    assert util.csr_digest(csr) == str(gc[f'{tag}.csr_sha256']), 'the synthetic transfer matrix differs from the fixture\'s'
+    _, md_in = util.load_md(model_root, a)
+    _, md_out = util.load_md(model_root, b)
+    ka, kb = a[:5] if a.startswith('smplx') else a, b[:5] if b.startswith('smplx') else b  # model family names
+    om_in = O.OracleModel(md_in, np.float32, ka)
+    om_out32, om_out = O.OracleModel(md_out, np.float32, kb), O.OracleModel(md_out, np.float64, kb)
+    pose, betas, trans, kid = (gc[f'{tag}.{k}'] for k in ('pose', 'betas', 'trans', 'kid'))
+    vin = om_in.forward(pose, betas, trans)['vertices'].astype(np.float32)
+    verts = np.stack([csr @ v for v in vin]).astype(np.float32)
+    assert np.abs(verts[:, ::97] - gc[f'{tag}.vertices_sub']).max() < 2e-6
+    kf = O.OracleFitter(om_out32, enable_kid=True)
+    for ni in (1, 3):
+        o = kf.fit(verts, None, num_iter=ni, beta_regularizer=0.0, final_adjust_rots=False, kid_regularizer=1e9)
+        util.check_convert(om_out, tag, f'it{ni}', {k: o[k] for k in ('pose_rotvecs', 'shape_betas', 'trans')}, gc)
+    o = kf.fit(verts, None, num_iter=1, beta_regularizer=0.0, final_adjust_rots=False, kid_regularizer=0.0)
+    util.check_convert(om_out, tag, 'kid.it1', {k: o[k] for k in ('pose_rotvecs', 'shape_betas', 'trans', 'kid_factor')}, gc)
+    o = kf.fit_with_known_shape(gc[f'{tag}.kshape.betas_in'], verts, None, num_iter=2, final_adjust_rots=False)
+    util.check_convert(om_out, tag, 'kshape', {k: o[k] for k in ('pose_rotvecs', 'trans')}, gc)
+    o = kf.fit_with_known_pose(gc[f'{tag}.kpose.pose_in'], verts, None, beta_regularizer=0.0, kid_regularizer=1e9)
+    util.check_convert(om_out, tag, 'kpose', {k: o[k] for k in ('shape_betas', 'trans')}, gc)

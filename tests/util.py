@@ -1,5 +1,6 @@
 """Shared helpers for the parity tests (oracle construction, metrics)."""
 
+import os
 import os.path as osp
 import sys
 
@@ -355,3 +356,64 @@ def check_share_scale(om, name, case, o, gk, kid_fit):
     va = om.forward(o['pose_rotvecs'], o['shape_betas'], o['trans'], **kw_o)['vertices']
     vb = om.forward(ref['pose_rotvecs'], ref['shape_betas'], ref['trans'], **kw_r)['vertices']
     assert np.linalg.norm(va - vb, axis=-1).max() < 5e-4, case
+
+
+# ---- cross-topology BodyConverter fixture (tests/golden/make_golden_convert.py) -----------------------
+CONVERT_DIRS = dict(s2x=('smpl', 'smplxfat'), x2s=('smplxfat', 'smpl'))  # golden-set names (load_md)
+
+
+def csr_digest(m):
+    """sha256 of a scipy CSR matrix as the fixture generator computes it."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for a in (m.indptr.astype(np.int64), m.indices.astype(np.int64), m.data.astype(np.float32)):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def load_transfer_csr(data_root, tag):
+    """The synthetic transfer matrix of direction ``tag`` in canonical CSR form, read from the official file layout
+    (first half of the columns, reference common.py:425-429)."""
+    import pickle
+
+    import scipy.sparse as sp
+
+    name = 'smpl2smplx_deftrafo_setup.pkl' if tag == 's2x' else 'smplx2smpl_deftrafo_setup.pkl'
+    with open(osp.join(data_root, 'body_models', name), 'rb') as f:
+        m = pickle.load(f)['mtx'].tocsr().astype(np.float32)
+    m = sp.csr_matrix(m[:, : m.shape[1] // 2].toarray())
+    return m
+
+
+def check_convert(om_out, tag, case, o, gc):
+    """Assertions of one ``convert`` result against the reference's cross-topology fixture.  The converted mesh does
+    not lie in the output model's space (synthetic models of unrelated shape), so the parameters are only pinned
+    through the mesh they produce: max vertex L2 <= 1e-4 m, translation 2e-5."""
+    pre = f'{tag}.{case}.'
+    keys = sorted(k[len(pre):] for k in gc if k.startswith(pre) and not k.endswith('_in'))
+    assert set(o) == set(keys), (tag, case, sorted(o), keys)
+    ref = {k: gc[pre + k] for k in keys}
+    # kid ridge 0 with beta ridge 0: the kid direction is nearly a combination of the betas' (and of a translation of
+    # the mesh), so there only the mesh is pinned
+    if case != 'kid.it1':
+        assert np.abs(o['trans'] - ref['trans']).max() < 2e-5, (tag, case, float(np.abs(o['trans'] - ref['trans']).max()))
+    if case == 'kshape':
+        betas = gc[f'{tag}.kshape.betas_in']
+        a = dict(pose_rotvecs=o['pose_rotvecs'], shape_betas=betas, trans=o['trans'])
+        b = dict(pose_rotvecs=ref['pose_rotvecs'], shape_betas=betas, trans=ref['trans'])
+    elif case == 'kpose':
+        pose = gc[f'{tag}.kpose.pose_in']
+        a = dict(pose_rotvecs=pose, shape_betas=o['shape_betas'], trans=o['trans'])
+        b = dict(pose_rotvecs=pose, shape_betas=ref['shape_betas'], trans=ref['trans'])
+    else:
+        a, b = o, ref
+    kw_a = dict(kid_factor=o['kid_factor']) if 'kid_factor' in o else {}
+    kw_b = dict(kid_factor=ref['kid_factor']) if 'kid_factor' in ref else {}
+    va = om_out.forward(a['pose_rotvecs'], a['shape_betas'], a['trans'], **kw_a)['vertices']
+    vb = om_out.forward(b['pose_rotvecs'], b['shape_betas'], b['trans'], **kw_b)['vertices']
+    err = float(np.linalg.norm(va - vb, axis=-1).max())
+    if os.getenv('SMPLFIT_TEST_VERBOSE'):
+        print(f'[convert] {tag} {case}: vertex L2 {err:.2e}, trans {np.abs(o["trans"] - ref["trans"]).max():.1e}')
+    assert err < 1e-4, (tag, case, err)
+    return err

@@ -30,6 +30,17 @@ def timeit(name, fn, steps=10):
 
 
 timeit('BodyModel.forward', lambda: m(pose, betas, trans))
+# cross-topology conversion on the synthetic transfer files (SMPL <-> the SMPL-X-shaped model)
+os.environ['DATA_ROOT'] = synth.write_transfer_files('/tmp/smplfit_bench_data')
+rootx = synth.ensure_model_root(kinds=('smplx',))
+mx = BodyModel('smplx', 'neutral', model_root=f'{rootx}/smplx', num_betas=10, device=dev)
+cx = BodyConverter(m, mx)
+vin = m(pose, betas, trans)['vertices']
+timeit('convert_vertices SMPL->SMPL-X (smplfit_transfer_f32)', lambda: cx.convert_vertices(vin))
+timeit('BodyConverter(SMPL->SMPL-X).convert (num_iter=1)', lambda: cx.convert(pose, betas, trans, num_iter=1))
+timeit('BodyConverter(SMPL->SMPL-X).convert (num_iter=3)', lambda: cx.convert(pose, betas, trans, num_iter=3))
+del cx, mx, vin
+torch.cuda.empty_cache()
 timeit('BodyConverter.convert (num_iter=1)', lambda: conv.convert(pose, betas, trans, num_iter=1))
 timeit('BodyConverter.convert (num_iter=3)', lambda: conv.convert(pose, betas, trans, num_iter=3))
 timeit('fit joints omitted (num_iter=3)', lambda: f.fit(fw['vertices'], None, num_iter=3))
