@@ -2,6 +2,7 @@
 #include "sf_tables.h"
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
@@ -303,8 +304,10 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
     for (int i = 0; i < Vp; ++i) pack(t.cpackA.data() + (size_t)i * cs, i);
     // vertex groups: greedy runs inside a part with at most kGroupJoints distinct joints
     t.groups.clear();
-    const int bs = t.brec_stride(), bw = t.brec_w(), bd = t.brec_d();
+    const int bs = t.brec_stride(), bw = t.brec_w();
     t.brec.assign((size_t)Vp * bs, 0.f);
+    t.pieces.clear();
+    t.piece_start.assign(1, 0);
     // A maximal run is then cut into equal pieces of at most `cap` vertices: the groups are the
     // workgroup units of the batch-major kernels, and SMPL's 22 runs of 224..483 vertices leave the chip
     // with uneven rounds of workgroups.  Measured at B = 4096 with two chunks (M fits/s): no cut 1.43,
@@ -322,9 +325,9 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
         ++e;
       }
       if (e == i) return "smplfit_create: a vertex has more skinning joints than a vertex group holds";
-      const int pieces = (e - i + cap - 1) / cap;
-      for (int pc = 0; pc < pieces; ++pc) {
-        const int a = i + (int)((int64_t)(e - i) * pc / pieces), b = i + (int)((int64_t)(e - i) * (pc + 1) / pieces);
+      const int npc = (e - i + cap - 1) / cap;
+      for (int pc = 0; pc < npc; ++pc) {
+        const int a = i + (int)((int64_t)(e - i) * pc / npc), b = i + (int)((int64_t)(e - i) * (pc + 1) / npc);
         VertexGroup g{};
         g.start = a;
         g.count = b - a;
@@ -339,29 +342,53 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
             g.joints[g.nq++] = j;
           }
         for (int q = g.nq; q < kGroupJoints; ++q) g.joints[q] = g.joints[0];
+        // the waves' shares (the kernels split [start, start + count) the same way) and their pieces
+        const int per = (g.count + kBmWaves - 1) / kBmWaves;
+        for (int w = 0; w < kBmWaves; ++w) {
+          const int wa = std::min(a + w * per, b), wb = std::min(wa + per, b);
+          size_t first = t.pieces.size();
+          // (models with more than four weights per vertex never take the batch-major kernels: no pieces)
+          for (int s = wa; s < wb && t.KW == 4;) {
+            uint64_t u = 0;
+            int e2 = s;
+            while (e2 < wb) {
+              const uint64_t u2 = u | jmask[t.perm[e2]];
+              if (__builtin_popcountll(u2) > 4) break;
+              u = u2;
+              ++e2;
+            }
+            if (e2 == s) return "smplfit_create: a vertex of the batch-major tables has more than 4 skinning joints";
+            int32_t rec[kPieceRec] = {0};
+            int nj = 0, pj[4] = {0, 0, 0, 0};
+            for (int j = 0; j < J; ++j)
+              if ((u >> j) & 1) pj[nj++] = j;
+            if (nj == 0) pj[nj++] = g.joints[0];  // (a vertex without weights: cannot happen for a valid model)
+            for (int k = nj; k < 4; ++k) pj[k] = pj[0];  // padding joints carry weight 0
+            rec[0] = e2 - s;  // vertices of the piece (the pieces of a wave are contiguous from its first slot)
+            for (int k = 0; k < 4; ++k) {
+              rec[1 + k] = pj[k];
+              rec[5 + k] = local[pj[k]];
+            }
+            t.pieces.insert(t.pieces.end(), rec, rec + kPieceRec);
+            for (int v = s; v < e2; ++v) {  // the vertex's weights in the piece's joint order
+              float* r = t.brec.data() + (size_t)v * bs;
+              for (int k = 0; k < nj; ++k) r[bw + k] = d.weights[(size_t)t.perm[v] * J + pj[k]];
+            }
+            s = e2;
+          }
+          (void)first;
+          t.piece_start.push_back((int32_t)(t.pieces.size() / kPieceRec));
+        }
         for (int s = a; s < b; ++s) {
           float* rec = t.brec.data() + (size_t)s * bs;
-          for (int s2 = 0; s2 < S; ++s2) {
+          for (int s2 = 0; s2 < S; ++s2)
             for (int c = 0; c < 3; ++c) rec[c * S + s2] = t.sd[(size_t)(c * S + s2) * Vp + s];
-          }
-          for (int k = 0; k < t.KW; ++k) rec[bw + k] = t.wval[(size_t)k * Vp + s];
-          for (int q = 0; q < t.KW / 4; ++q) {
-            uint32_t w = 0;
-            for (int k = 0; k < 4; ++k) {
-              const int pair = q * 4 + k;
-              const float wv = t.wval[(size_t)pair * Vp + s];
-              const int jj = (int)((t.widx[(size_t)q * Vp + s] >> (8 * k)) & 0xffu);
-              const int ls = wv != 0.f ? local[jj] : 0;  // zero-weight padding pairs point at slot 0
-              w |= (uint32_t)ls << (8 * k);
-              if (wv != 0.f) rec[bd + ls] += wv;
-            }
-            std::memcpy(rec + bw + t.KW + q, &w, 4);
-          }
         }
         t.groups.push_back(g);
       }
       i = e;
     }
+    t.pieces.insert(t.pieces.end(), kPieceRec, 0);  // sentinel: a zero-length piece behind the last one
     if (std::getenv("SMPLFIT_DUMP_GROUPS"))
       for (const auto& g : t.groups)
         std::fprintf(stderr, "group start %d count %d part %d used %d nq %d\n", g.start, g.count, g.part, g.used, g.nq);

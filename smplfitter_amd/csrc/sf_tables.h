@@ -32,6 +32,14 @@ struct Segment {
 // whose skinning joints number at most kGroupJoints; the group's joint list is staged once per
 // workgroup and the per-vertex records address it by local slot.
 constexpr int kGroupJoints = 12;
+constexpr int kBmWaves = 4;   // waves of a batch-major vertex workgroup: they split the group's vertices evenly
+// A wave's share of a group is cut into PIECES: maximal runs of slots whose skinning joints number at most four
+// together.  Inside a piece the vertex loops keep those four joints' records in registers (no LDS read per vertex)
+// and the per-joint sums in four accumulators; a vertex's record holds its weights in the piece's joint order.
+// Record: the piece's vertex count (a wave's pieces are contiguous from its first slot), joints[4] (model joint ids,
+// ascending, padded with the first), local[4] (their slots in the group's joint list), 3 unused.  The table ends
+// with one all-zero record, so that reading one record past a wave's last piece is always valid.
+constexpr int kPieceRec = 12;
 struct VertexGroup {
   int32_t start, count, part, used, nq;
   int32_t joints[kGroupJoints];  // padded with joints[0]
@@ -124,12 +132,12 @@ struct HostTables {
   std::vector<float> diag_c2e;   // diag_c2 as (J, 3, SE)
   int s_even() const { return (S + 1) & ~1; }
   // brec row (brec_stride() floats, fetched with scalar loads): [sd_x : S][sd_y : S][sd_z : S][pad to a
-  // multiple of 4][KW weights][KW/4 words of local joint slots][pad to 4][dense weights over the group's
-  // joint list : kGroupJoints]
+  // multiple of 4][4 weights in the joint order of the vertex's piece]
   std::vector<float> brec;       // (Vp, brec_stride())
-  int brec_w() const { return (3 * S + 3) / 4 * 4; }                   // offset of the weights
-  int brec_d() const { return brec_w() + (KW + KW / 4 + 3) / 4 * 4; }  // offset of the dense weights
-  int brec_stride() const { return brec_d() + kGroupJoints; }
+  int brec_w() const { return (3 * S + 3) / 4 * 4; }  // offset of the weights
+  int brec_stride() const { return brec_w() + 4; }
+  std::vector<int32_t> pieces;       // (npieces, kPieceRec)
+  std::vector<int32_t> piece_start;  // (ngroups * kBmWaves + 1) first piece of every (group, wave)
   std::vector<float> gblob;      // (ngt, gblob_stride())
   int gblob_stride() const { return 64 * cstride() + 16 * 64 + 16; }
 

@@ -80,7 +80,9 @@ struct DevModel {
   // table order with the group index fastest
   const int32_t *gorder_all, *gorder_used;
   int lpt;
-  const float* brec;
+  const float* brec;          // (Vp, brec_stride) per-slot records: shapedirs + 4 weights in the piece's joint order
+  const int32_t* pieces;      // (npieces, kPieceRec) joint runs of every (group, wave), HostTables::pieces
+  const int32_t* piece_start; // (ngroups * kBW + 1)
   const float *pair_c1x, *pair_c2e, *diag_c2e;  // even-stride copies for k_pair_gram_bm (HostTables)
   // per joint: the resP rows (group * kResRec + 16 + 3 * slot) holding its residual moments
   const int32_t *mb_start, *mb_row;
@@ -267,6 +269,8 @@ struct Tuning {
   int gemm_nchunk = 0;     // SMPLFIT_GEMM_NCHUNK: column-tile chunks of the split-bf16 GEMM (0 = automatic)
   int gemm_lds_kb = 0;     // SMPLFIT_GEMM_LDS_KB: LDS request of the fp32 A-stationary GEMM (occupancy experiments)
   int lpt = 1;             // SMPLFIT_LPT=0: vertex groups launched in table order (read at smplfit_create)
+  int bm_lds_kb = 0;       // SMPLFIT_BM_LDS_KB: LDS request of the two batch-major vertex passes padded to this (54: three
+                           // workgroups per CU instead of four, which leaves registers / LDS for another chunk's small kernels)
 };
 Tuning g_tune;
 std::once_flag g_tune_once;
@@ -281,6 +285,7 @@ void load_tuning() {
   if (const char* e = env("SMPLFIT_GEMM_NCHUNK")) t.gemm_nchunk = std::max(1, atoi(e));
   if (const char* e = env("SMPLFIT_GEMM_LDS_KB")) t.gemm_lds_kb = atoi(e);
   if (const char* e = env("SMPLFIT_LPT")) t.lpt = atoi(e);
+  if (const char* e = env("SMPLFIT_BM_LDS_KB")) t.bm_lds_kb = std::min(std::max(atoi(e), 0), 64);
   g_tune = t;
 }
 const Tuning& tune() {
@@ -336,7 +341,7 @@ void launch_residual_bm_s(const DevModel& d, const Workspace& ws, int B, hipStre
   const int Mp = (int)align_up((size_t)B, 128);
   if (which & 1)
     hipLaunchKernelGGL((k_residual_bm<S>), d.lpt ? dim3(Mp / 64, d.ngroups) : dim3(d.ngroups, Mp / 64),
-                       dim3(64 * kBW), kResidualLds, st, d, ws, B, Mp);
+                       dim3(64 * kBW), std::max(kResidualLds, (size_t)tune().bm_lds_kb * 1024), st, d, ws, B, Mp);
   if (which & 2) {
     if constexpr (S > 10) {  // two launches over the rows of the Gramian (see k_pair_gram_bm)
       hipLaunchKernelGGL((k_pair_gram_bm<S, 1>), dim3(kGramChunks, Mp / 64), dim3(64), 0, st, d, ws, B, Mp);
@@ -359,8 +364,8 @@ void launch_residual_bm(const DevModel& d, const Workspace& ws, int B, hipStream
 template <int S, int KW>
 void launch_lbs_bm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, bool write_v = false) {
   const int Mp = (int)align_up((size_t)B, 128);
-  const size_t lds = (size_t)kGQ * 12 * 64 * 4;
-  if constexpr (KW == 4) {
+  const size_t lds = std::max(kLbsLds, (size_t)tune().bm_lds_kb * 1024);
+  if constexpr (KW == 4 && S <= 12) {  // what bm_applies admits (10 betas with or without the kid unknown)
     if (write_v) {
       hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4, true>), d.lpt ? dim3(Mp / 64, d.ngroups) : dim3(d.ngroups, Mp / 64),
                          dim3(64 * kBW), lds, st, d, ws, B, Mp);
@@ -911,7 +916,7 @@ int launch_convert_source(const ConvertSource& src, const DevModel& d, const Wor
   if (int rc = launch_gemm(di, wi, B, st, true)) return rc;
   launch_jd_transpose(di, wi, B, st);
   {
-    const size_t lds = (size_t)kGQ * 12 * 64 * 4;
+    const size_t lds = kLbsLds;
     const dim3 grid = di.lpt ? dim3(Mp / 64, di.ngroups) : dim3(di.ngroups, Mp / 64);
     if (di.S == 11)
       hipLaunchKernelGGL((k_lbs_partsum_bm<11, 4, true, true>), grid, dim3(64 * kBW), lds, st, di, wi, B, Mp);
@@ -1225,6 +1230,8 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
     up(mb_start, &d.mb_start);
     up(mb_row, &d.mb_row);
     up(t.brec, &d.brec);
+    up(t.pieces, &d.pieces);
+    up(t.piece_start, &d.piece_start);
     up(t.pair_c1x, &d.pair_c1x);
     up(t.pair_c2e, &d.pair_c2e);
     up(t.diag_c2e, &d.diag_c2e);
