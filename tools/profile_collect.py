@@ -26,8 +26,15 @@ def trace_rows(d):
     return rows
 
 
-def stats_csv(rows, path, head):
-    t_lo = rows[0][0] + (rows[-1][1] - rows[0][0]) // 3  # steady state: skip set-up and warm-up
+def stats_csv(rows, path, head, chunks, warm=3):
+    # steady state = the timed fits of the bench command: every fit ends with one k_refine_epilogue per chunk; the
+    # window opens when the last warm-up fit has ended and closes with the last timed fit (bench.py's roofline leg —
+    # repeated single-kernel launches — comes after it and is left out)
+    ends = sorted(e for s, e, n in rows if short(n) == 'k_refine_epilogue')
+    t_lo, t_hi = ends[warm * chunks - 1], ends[-1]
+    nfit = (len(ends) - warm * chunks) // chunks
+    head += f'; statistics over the {nfit} timed fits (window between the {warm}rd and the last k_refine_epilogue)'
+    rows = [r for r in rows if r[0] >= t_lo and r[1] <= t_hi]
     per = collections.defaultdict(list)
     for s, e, n in rows:
         if s >= t_lo:
@@ -45,18 +52,19 @@ def stats_csv(rows, path, head):
         if depth >= 2: b2 += tme - last
         depth += dl; last = tme
     span = ev[-1][0] - ev[0][0]
-    return f'{os.path.basename(path)}: span {span/1e6:.2f} ms, kernel time summed {tot/1e3:.2f} ms, >= 1 kernel in flight {100*b1/span:.1f} %, >= 2 kernels {100*b2/span:.1f} %'
+    return (f'{os.path.basename(path)}: {nfit} fits, span {span/1e6:.2f} ms ({span/1e3/nfit:.1f} us per fit), kernel time summed '
+            f'{tot/1e3:.2f} ms ({tot/nfit:.1f} us per fit), >= 1 kernel in flight {100*b1/span:.1f} %, >= 2 kernels {100*b2/span:.1f} %')
 
 
 bench = json.load(open(f'{src}/bench_default.json'))
 build = bench['build']
 head = f'rocprofv3 --kernel-trace of `python bench.py --steps 10 --warmup 3 --no-cpu-baseline`, build "{build}", git HEAD see profiles/README.md'
 lines = []
-for sub, name, extra in (('trace1', f'{tag}_kernel_stats_chunks1.csv', 'SMPLFIT_CHUNKS=1 (4096-instance launches)'),
-                         ('trace2', f'{tag}_kernel_stats.csv', 'default chunking (two 2048-instance chunks on two streams)')):
+for sub, name, extra, nch in (('trace1', f'{tag}_kernel_stats_chunks1.csv', 'SMPLFIT_CHUNKS=1 (4096-instance launches)', 1),
+                              ('trace2', f'{tag}_kernel_stats.csv', 'default chunking (two 2048-instance chunks on two streams)', 2)):
     rows = trace_rows(f'{src}/{sub}')
     if rows:
-        lines.append(stats_csv(rows, f'{DST}/{name}', head + '; ' + extra))
+        lines.append(stats_csv(rows, f'{DST}/{name}', head + '; ' + extra, nch))
 open(f'{DST}/{tag}_trace_summary.txt', 'w').write('\n'.join(lines) + '\n')
 
 # ---- PMC: mean counter value per dispatch per kernel (steady-state dispatches of the fit only)
