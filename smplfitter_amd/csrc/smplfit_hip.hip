@@ -1175,6 +1175,9 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
     }
     h->gemm_vgprs = regs;
     d.gemm_exclusive = regs >= 256 ? 1 : 0;
+#ifdef SMPLFIT_GEMM_SHARED_CU  // debug builds of tools/dbg_pg.py: the split GEMM on shared CUs, to study the interaction
+    d.gemm_exclusive = 1;
+#endif
   }
   std::vector<uint16_t>().swap(h->t.pdB2);  // the host copy of the stage images is not needed any more
   up(t.cpackA, &d.cpackA);
