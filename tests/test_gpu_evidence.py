@@ -292,6 +292,55 @@ def test_full_size_vs_oracle_samples_c3_c4(name, B, model_root, golden, dev):
     assert errs['vertex'] < 1e-4 and errs['betas'] < 1e-4 and errs['trans'] < 1e-5 and errs['pose'] < 3e-4, errs
 
 
+@pytest.mark.parametrize('name', ['smpl', 'smplx'])
+def test_workspace_guards(name, model_root, golden, dev):
+    """Stand-in for a device memcheck (the image has no ASAN-instrumented ROCm runtime, profiles/r03_asan_device.txt):
+    the per-call workspace is embedded between two 1 MB guard regions whose byte pattern must survive every call, and
+    is itself filled with NaN bit patterns before each call — a kernel reading a cell nobody wrote first would carry
+    NaN into the results, which must be finite and bit-identical to a run on a zeroed workspace.  Covers the default
+    two-chunk fit with a partial last instance block, the kid unknown, joints omitted, vertex weights (wave-per-
+    instance kernels) and a warm start."""
+    from smplfitter_amd.pt import BodyFitter
+
+    g = golden(name)
+    m, f = get_model(model_root, name, g, dev)
+    fk = BodyFitter(m, enable_kid=True)
+    B = 1100 if name == 'smpl' else 300
+    tv, tj = make_targets(m, B, 3, dev)
+    guard = 1 << 20
+    cases = [
+        (f, False, dict(num_iter=2, beta_regularizer=1.0)),
+        (fk, False, dict(num_iter=2, beta_regularizer=1.0)),
+        (f, True, dict(num_iter=2, beta_regularizer=1.0, target_joints=None)),
+        (f, False, dict(num_iter=2, vertex_weights=torch.rand(B, m.num_vertices, device=dev) + 0.5,
+                        joint_weights=torch.rand(B, m.num_joints, device=dev) + 0.5)),
+        (f, False, dict(num_iter=2, initial_pose_rotvecs=torch.zeros(B, 3 * m.num_joints, device=dev),
+                        initial_shape_betas=torch.zeros(B, 10, device=dev))),
+    ]
+    for fitter, no_joints, kw in cases:
+        kw = dict(kw)
+        kw.pop('target_joints', None)
+        h = m._native(dev, kid=fitter.enable_kid)
+        n = h.workspace_bytes(B)
+        buf = torch.empty(n + 2 * guard, dtype=torch.uint8, device=dev)
+        ws = buf[guard:guard + n]
+        assert ws.data_ptr() % 256 == 0
+        out = {}
+        for fill in ('zero', 'nan'):
+            buf.fill_(0xA5)
+            if fill == 'zero':
+                ws.zero_()
+            else:
+                ws.view(torch.int32).fill_(0x7FC00000 | 0x1234)  # quiet NaN pattern in every float / half a double
+            r = fitter.fit(tv, None if no_joints else tj, _workspace=ws, **kw)
+            torch.cuda.synchronize()
+            assert bool((buf[:guard] == 0xA5).all()) and bool((buf[guard + n:] == 0xA5).all()), 'guard region written'
+            out[fill] = {k: v.clone() for k, v in r.items()}
+            assert all(torch.isfinite(v).all() for v in r.values()), 'a result depends on uninitialised workspace'
+        for k in out['zero']:
+            assert torch.equal(out['zero'][k], out['nan'][k]), k
+
+
 def test_neighbour_stress(model_root, golden, dev):
     """The split-bf16 GEMM must never share a CU with another kernel (k_posedirs_gemm_bf16x3, "exclusive CU"): beside
     its LDS-fed bf16 MFMAs, other kernels' waves were seen to read wrong lanes.  The guard is an occupancy one (256
