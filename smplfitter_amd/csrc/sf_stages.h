@@ -332,7 +332,9 @@ SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const doubl
                        const float* gramj, const float* pext, const float* jd, const float* mb,
                        float beta_reg, float beta_reg2, float kid_reg, float* beta_out, float* trans_out,
                        float* rjoints_out, float* jb_out, const float* reg_ref = nullptr, int mode = 0,
-                       double* cen = nullptr) {
+                       double* cen = nullptr, float* jbT_out = nullptr) {
+  // jbT_out: the instance's column of the instance-innermost copy of jb ((J, 4) rows of 64 instances; element
+  // (j, c) at jbT_out[(j * 4 + c) * 64]) read by the batch-major LBS kernel
   const int J = tb.J, S = tb.S, S1 = S + 1;
   const int NG = ne_ng(S), NE = ne_size(S);
   double* sum = reinterpret_cast<double*>(scratch);  // NE+1   (scratch is 8-byte aligned)
@@ -435,6 +437,7 @@ SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const doubl
     const float* tr = jd + j * stride + 12 + c * row;
     for (int s = 0; s < S; ++s) tb0 += tr[s] * betaf[s];
     jb_out[j * 4 + c] = jd[j * stride + 9 + c] + tb0;
+    if (jbT_out) jbT_out[(j * 4 + c) * 64] = jd[j * stride + 9 + c] + tb0;
   }
 }
 

@@ -174,6 +174,7 @@ struct Workspace {
   float* beta;     // (B,S)
   float* trans;    // (B,3)
   float* jb;       // (B,J,4)
+  float* jbT;      // (Mp/64, J*4, 64) the same, instance-innermost (batch-major LBS kernel)
   float* rjoints;  // (B,J,3)
   float* rverts;   // (B,3,Vp) re-evaluated vertices (joints-omitted path only)
   float* tjreg;    // (B,J,3) regressed target joints (joints-omitted path)
@@ -227,6 +228,7 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w, bool fwd_
   ws.beta = (float*)take((size_t)B * S * 4, true);
   ws.trans = (float*)take((size_t)B * 3 * 4, true);
   ws.jb = (float*)take((size_t)B * J * 4 * 4, true);
+  ws.jbT = (float*)take(Mp * J * 4 * 4, true);
   ws.rjoints = (float*)take((size_t)B * J * 3 * 4, true);
   ws.rverts = (float*)take((size_t)B * 3 * Vp * 4);
   ws.tjreg = (float*)take((size_t)B * J * 3 * 4);

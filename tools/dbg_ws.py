@@ -25,7 +25,7 @@ def regions(Bc):
     Mp = au(Bc, 128); Kp = 208; jds = 52
     r = [('tvs', Bc*3*Vp*4), ('vws', Bc*Vp*4), ('vposed', Mp*3*Vp*4), ('rp', Mp*Kp*4), ('mean', Bc*12), ('tjc', Bc*J*12),
          ('psum', Bc*J*16*4), ('G', Bc*J*36), ('jd', Bc*J*jds*4), ('pext', Bc*J*3*(S+1)*4), ('gramj', Bc*(NE+1)*4),
-         ('gramv', Bc*(NE+1)*8), ('beta', Bc*S*4), ('trans', Bc*12), ('jb', Bc*J*16), ('rjoints', Bc*J*12), ('rverts', Bc*3*Vp*4),
+         ('gramv', Bc*(NE+1)*8), ('beta', Bc*S*4), ('trans', Bc*12), ('jb', Bc*J*16), ('jbT', Mp*J*16), ('rjoints', Bc*J*12), ('rverts', Bc*3*Vp*4),
          ('tjreg', Bc*J*12), ('rjreg', Bc*J*12), ('mbj', Bc*J*12), ('scale', Bc*4), ('regref', Bc*S*4), ('cen', (Bc+1)*(S*S+S)*8),
          ('vextra', Bc*32*4), ('beta_out', Bc*S*4), ('tjs', Bc*J*12), ('vpT', Mp*3*Vp*4), ('tT', Mp*3*Vp*4),
          ('psumP', ngroups*16*Mp*4), ('resP', ngroups*52*Mp*4), ('gramP', 32*NE*Mp*4), ('jdT', Mp*au(J*jds, 64)*4)]
