@@ -1,25 +1,22 @@
 // libsmplfit_hip.so — HIP kernels (gfx950 / CDNA4) and the C-ABI of include/smplfit.h.
 //
-// Kernel inventory.  Wave-per-instance kernels (every configuration; grid = instances unless noted):
-//   k_center_sort_partsum(_lds)  K0  mean-centre targets, re-order vertices by body part (SoA), part
-//                              sums against the template mesh      [HBM-bound streaming + wave sums]
-//   k_joint_stage          K1  part rotations (SO(3) projections, swing-twist), shape prologue
-//                              (FK + beta-Jacobian, pose feature, joint normal equations)  [1 wave]
-//   k_posedirs_gemm(_as)   K2  v_posed = v_template + pose_feature . posedirs, fp32 MFMA 32x32x2,
-//                              A-stationary (SMPL) or 128x128 LDS-tiled; plain or instance-innermost
-//                              output                                                    [MFMA-bound]
-//   k_shape_accum          K3  per-vertex blended rotation / position / shape Jacobian from LDS
-//                              joint block, 98 normal-equation sums per instance         [VALU-bound]
-//   k_residual, k_pair_gram    the same block in pair-Gram form (SMPLFIT_SHAPE_FORM=pair)
-//   k_shape_solve          K4  fp64 centring + 10x10 Cholesky + translation (share_beta: + k_share_reduce;
-//                              scale options: k_scale_extras + k_shape_solve_scaled + k_scale_refs)
-//   k_lbs_partsum          K5  vertices at the solved shape (LBS) fused with the part sums of the
-//                              next rotation pass — the re-evaluated mesh never reaches HBM
-//   k_refine_epilogue      K6  dependent rotation refinement + relative rotations + log map [1 wave]
+// Kernel inventory (DESIGN.md §2, §4).  Wave-per-instance kernels (every configuration; grid = instances unless noted):
+//   k_center_sort_partsum(_lds)  K0  mean-centre targets, re-order vertices by body part (SoA), part sums against
+//                                    the template mesh
+//   k_joint_stage          K1  part rotations (SO(3) projections, swing-twist), shape prologue (FK + beta-Jacobian,
+//                              pose feature, joint normal equations)
+//   k_posedirs_gemm*       K2  v_posed = v_template + pose_feature . posedirs: split-bf16 on the matrix cores
+//                              (k_posedirs_gemm_bf16x3, _tiled for K > 208) or fp32 MFMA (_as, generic)
+//   k_shape_accum          K3  vertex block of the normal equations (weighted / non-batch-major configurations)
+//   k_shape_solve          K4  fp64 centring + Cholesky + translation (share_beta: + k_share_reduce; scale options:
+//                              k_scale_extras + k_shape_solve_scaled + k_scale_refs)
+//   k_lbs_partsum          K5  vertices at the solved shape fused with the part sums of the next rotation pass
+//   k_refine_epilogue      K6  dependent rotation refinement + relative rotations + log map
 //   k_forward_joint, k_lbs_partsum<MODE 2>   BodyModel.forward;  k_scale_trans  known-shape alignment
-// Batch-major kernels (LANE = INSTANCE; the default vertex block where they apply, see bm_applies):
-//   k_transpose_targets, k_residual_bm, k_pair_gram_bm, k_gram_combine_bm, k_lbs_partsum_bm,
-//   k_psum_combine — grid = (vertex group | unit chunk) x instance blocks of 64.
+// Batch-major kernels (LANE = INSTANCE; the default vertex block where they apply, see bm_applies): k_layout_targets,
+//   k_mean_finish, k_template_partsum_bm, k_residual_bm, k_pair_gram_bm, k_gram_combine_bm, k_lbs_partsum_bm,
+//   k_psum_combine, k_regress_joints_bm, k_transpose_targets (joint rows) — grid = (vertex group | unit chunk) x
+//   instance blocks of 64; k_transfer_bm / k_transfer_rows: topology transfer (BodyConverter).
 // Everything is enqueued on the caller's stream; no host synchronisation, no allocation.
 #include <hip/hip_runtime.h>
 
@@ -946,9 +943,9 @@ int upload(smplfit_handle* h, const std::vector<T>& src, const T** dst) {
   return 0;
 }
 
-// Chunk plan of one fit call: large batches are split into chunks (default 3, SMPLFIT_CHUNKS=1..4) that run concurrently on
-// the caller's stream and the handle's side streams, so that the MFMA-bound posedirs GEMM of one
-// chunk overlaps the VALU / HBM-bound vertex passes of the others (measured +5 % at B = 4096).
+// Chunk plan of one fit call: large batches are split into chunks (default 2, SMPLFIT_CHUNKS=1..4) that run concurrently on
+// the caller's stream and the handle's side streams, so that the small latency-bound kernels of one chunk run beside
+// the heavy kernels of the other (measured +4 % at B = 4096; the GEMM itself never shares a CU).
 // Chunk sizes are multiples of 128 (the GEMM's instance tile).
 int chunk_plan(int batch, int* sizes) {
   int n = std::min(tune().chunks, kMaxChunks);  // default 2; measured at B = 4096: 1 chunk 1.73, 2: 1.79, 3: 1.75, 4: 1.74 M fits/s
