@@ -270,7 +270,10 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
       std::memcpy(&f, &u, 4);
       return f;
     };
-    t.pdB.assign((size_t)ntile * 3 * 32 * Kp, 0);
+    // elements of one tile image: three full planes, or (three products) two full planes + the lo plane of the last
+    // k-step, [32 n][2 slots][8 k]
+    const size_t plane = (size_t)32 * Kp, tile = kGemm3 ? 2 * plane + 32 * 16 : 3 * plane;
+    t.pdB.assign((size_t)ntile * tile, 0);
     for (int nt = 0; nt < ntile; ++nt)
       for (int n = 0; n < 32; ++n)
         for (int k = 0; k < Kp; ++k) {
@@ -280,10 +283,11 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
           const uint16_t m = bf16_rne(r1);
           const uint16_t l = bf16_rne(r1 - bf16_f32(m));
           const int slot = (k >> 3) ^ ((n >> 3) & 1);
-          const size_t base = (((size_t)nt * 3) * 32 + n) * Kp + (size_t)slot * 8 + (k & 7);
+          const size_t base = (size_t)nt * tile + (size_t)n * Kp + (size_t)slot * 8 + (k & 7);
           t.pdB[base] = h;
-          t.pdB[base + (size_t)32 * Kp] = m;
-          t.pdB[base + (size_t)64 * Kp] = l;
+          t.pdB[base + plane] = m;
+          if (!kGemm3) t.pdB[base + 2 * plane] = l;
+          else if (k >= Kp - 16) t.pdB[(size_t)nt * tile + 2 * plane + (size_t)n * 16 + ((k >> 3) & 1) * 8 + (k & 7)] = l;
         }
     (void)nslot;
   }

@@ -20,6 +20,12 @@ constexpr int kMaxJoints = 64;
 constexpr int kTile = 64;        // wave width
 constexpr int kVertexPad = 128;  // Vp granularity (GEMM N tile = 128 divides 3*Vp)
 constexpr int kGemmKPad = 16;    // posedirs K padded to the GEMM K step
+// Products per k-step of the split-bf16 posedirs GEMMs (see kernels_wave.inc, kGemm3): 3 by default.  The host images
+// of posedirs depend on it (with three products the third bf16 plane is only kept for the k-step of the bias row).
+#ifndef SMPLFIT_GEMM_PRODUCTS
+#define SMPLFIT_GEMM_PRODUCTS 3
+#endif
+constexpr bool kGemm3 = SMPLFIT_GEMM_PRODUCTS == 3;
 constexpr int kJdStride = 52;    // floats per joint in the per-instance joint block (see sf_stages.h)
 
 enum PartType : int32_t { kPartNone = 0, kPartMulti = 1, kPartBone = 2, kPartLeaf = 3 };
@@ -85,13 +91,15 @@ struct HostTables {
   std::vector<float> wval;      // (KW, Vp)
   std::vector<float> pdT;       // (Kp, 3*Vp) posedirs, K-major, rows in rp_pos() (parity-major) order; row rp_pos(P) = v_template
   std::vector<float> pdSw;      // (3*Vp/32, 32, Kp) the same, transposed per 32-column tile (A-stationary GEMM)
-  // Split-bf16 image of pdSw for the matrix-core GEMM (Kp == 208 only): per 32-column tile three planes
-  // (hi, mid, lo with hi + mid + lo == the fp32 value, each rounded to nearest bf16) of [32 n][26 slots][8 k],
-  // slot = k / 8 with bit 0 flipped for rows with (n >> 3) & 1 (bank-conflict-free 16-byte LDS reads from
-  // unpadded 416-byte rows).  The tile image is copied to LDS verbatim.
+  // Split-bf16 image of pdSw for the matrix-core GEMM (Kp == 208 only): per 32-column tile the planes hi, mid (, lo;
+  // hi + mid + lo == the fp32 value, each rounded to nearest bf16) of [32 n][26 slots][8 k], slot = k / 8 with bit 0
+  // flipped for rows with (n >> 3) & 1 (bank-conflict-free 16-byte LDS reads from unpadded 416-byte rows).  With
+  // three products per k-step (kGemm3) the lo plane is kept for the LAST k-step only (the bias row's: [32 n][2 slots][8 k],
+  // slot = (k / 8) & 1), 27 KB per tile instead of 39.  The tile image is copied to LDS verbatim.
   std::vector<uint16_t> pdB;
   // split-bf16 stage images of posedirs for the tiled GEMM (Kp != 208, e.g. SMPL-X): per 128-column tile and
   // 32-k stage three planes [128 n][4 slots][8 k] (24 KB), slot = (k >> 3) ^ ((n >> 2) & 3); K padded to kc32 * 32
+  // (with three products per k-step the kernel copies the third plane for the bias row's stage only)
   std::vector<uint16_t> pdB2;
   int kc32 = 0;  // stages of 32 k
   // per-vertex constants packed per 64-vertex tile for cooperative staging through LDS:

@@ -210,8 +210,8 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w, bool fwd_
   ws.tvs = (float*)take((size_t)B * 3 * Vp * 4);
   ws.vws = (float*)take((size_t)B * Vp * 4);
   // instance-major GEMM output; on the batch-major path of a model with Kp != 208 it holds the split feature
-  // images of the tiled GEMM instead (k_split_features: 48 KB per 256-instance tile and 32-k stage)
-  ws.vposed = (float*)take(fwd_only ? (t.Kp != 208 ? (Mp + 255) / 256 * (size_t)((t.Kp + 31) / 32) * 49152 : 0)
+  // images of the tiled GEMM instead (k_split_features: 32 KB per 256-instance tile and 32-k stage)
+  ws.vposed = (float*)take(fwd_only ? (t.Kp != 208 ? (Mp + 255) / 256 * (size_t)((t.Kp + 31) / 32) * ((sf::kGemm3 ? 2 : 3) * 256 * 64) : 0)
                                     : Mp * 3 * Vp * 4, true);
   ws.rp = (float*)take(Mp * t.Kp * 4, true);
   ws.mean = (float*)take((size_t)B * 3 * 4);
@@ -479,9 +479,9 @@ int check_common(const smplfit_handle* h, int batch, void* workspace, size_t wor
 }
 
 // Arithmetic of the posedirs contraction: "bf16x3" (default) runs it on the bf16 matrix cores with every fp32
-// operand split error-free into three bf16 terms (6 products per k, fp32 accumulate: fp32-equivalent accuracy,
-// see k_posedirs_gemm_bf16x3); "f32" (SMPLFIT_GEMM=f32) uses the fp32 MFMA, which on gfx950 shares the vector
-// ALUs with ordinary VALU work.
+// operand split error-free into bf16 terms (3 products per k-step + the bias row's third term, fp32 accumulate:
+// fp32-class accuracy at the vertex level, see k_posedirs_gemm_bf16x3); "f32" (SMPLFIT_GEMM=f32) uses the fp32 MFMA,
+// which on gfx950 shares the vector ALUs with ordinary VALU work.
 bool gemm_bf16x3() { return !tune().gemm_f32; }
 
 int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, bool transposed = false) {
@@ -528,7 +528,7 @@ int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, b
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     hipLaunchKernelGGL(k_posedirs_gemm_bf16x3_tiled, dim3(8 * ((mt + 7) / 8) * nt128), dim3(512), (size_t)2 * kTgStage, st,
-                       aimg, d.pdB2, ws.vpT, N, Mp, mt, d.kc32);
+                       aimg, d.pdB2, ws.vpT, N, Mp, mt, d.kc32, sf::rp_pos(d.P, d.Kp) / 16);
     return 0;
   }
   if (d.Kp == 208) {  // SMPL (J = 24): A-stationary kernel, 104 A registers per lane

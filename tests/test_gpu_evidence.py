@@ -162,10 +162,12 @@ def test_parity_statistics(name, model_root, golden, dev, capsys):
 
 
 def test_gemm_split_precision(model_root, golden, dev, smplfit_env):
-    """The posedirs contraction on the bf16 matrix cores (three-way error-free split of both fp32 operands,
-    six products, fp32 accumulate: k_posedirs_gemm_bf16x3, the default) is fp32-equivalent: against the
-    fp64 oracle its forward mesh is as accurate as the one computed with the fp32 MFMA (SMPLFIT_GEMM=f32),
-    on small and on large rotations (pose features of order 1), and whole fits agree to the last digits."""
+    """The posedirs contraction on the bf16 matrix cores (error-free bf16 split of both fp32 operands, three products
+    per k-step + the bias row's third term, fp32 accumulate: k_posedirs_gemm_bf16x3, the default) is fp32-class at the
+    vertex level: against the fp64 oracle its forward mesh is as accurate as the one computed with the fp32 MFMA
+    (SMPLFIT_GEMM=f32; gate: <= 1.5x its error + 5e-8 m, and < 2e-6 m absolute), on small and on large rotations (pose
+    features of order 1: the pose-corrective offsets, where the dropped 2^-18 terms live, are then largest), and whole
+    fits agree to the last digits."""
     g = golden('smpl')
     kind, md = util.load_md(model_root, 'smpl', g)
     om64, _ = util.make_oracle(md, kind, np.float64)
