@@ -1177,6 +1177,9 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
 #ifdef SMPLFIT_GEMM_SHARED_CU  // debug builds of tools/dbg_pg.py: the split GEMM on shared CUs, to study the interaction
     d.gemm_exclusive = 1;
 #endif
+    // the A-stationary split kernel (Kp == 208) gives the bias row its third term in the LAST k-step, where SMPL's
+    // 207 pose features put it; a model with Kp == 208 whose bias row sits elsewhere takes the fp32-MFMA GEMM
+    if (sf::kGemm3 && t.Kp == 208 && sf::rp_pos(t.P, t.Kp) / 16 != kGemmKS - 1) d.gemm_exclusive = 0;
   }
   std::vector<uint16_t>().swap(h->t.pdB2);  // the host copy of the stage images is not needed any more
   up(t.cpackA, &d.cpackA);
