@@ -57,6 +57,16 @@ def test_forward_goldens(name, model_root, golden, dev):
     assert np.abs(fw['orientations'] - g['fwd_orientations']).max() < 1e-6
     fw2 = to_np(m(shape_betas=t(g['betas'], dev), trans=t(g['trans'], dev), glob_rotmats=t(g['fwd_orientations'], dev)))
     assert np.abs(fw2['vertices'] - g['target_vertices']).max() < 5e-6
+    # rel_rotmats (pt/bodymodel.py:230-234): the kinematic chain runs inside the joint kernel (smplfit_forward_ex_f32)
+    G = g['fwd_orientations']
+    par = np.asarray(m.kintree_parents)
+    rel = G.astype(np.float64)
+    rel[:, 1:] = np.einsum('bjxy,bjxz->bjyz', rel[:, par[1:]], rel[:, 1:])  # parent^T @ global (fp64, rounded once)
+    fw3 = to_np(m(shape_betas=t(g['betas'], dev), trans=t(g['trans'], dev), rel_rotmats=t(rel.astype(np.float32), dev)))
+    assert np.abs(fw3['vertices'] - g['target_vertices']).max() < 5e-6
+    assert np.abs(fw3['orientations'] - G).max() < 5e-6  # an 8-level chain of fp32 products of rounded factors
+    with pytest.raises(ValueError):
+        m(pose_rotvecs=t(g['pose'], dev), rel_rotmats=t(rel.astype(np.float32), dev))
     j = to_np(m(t(g['pose'], dev), t(g['betas'], dev), t(g['trans'], dev), return_vertices=False))
     assert 'vertices' not in j and np.abs(j['joints'] - g['fwd_joints']).max() < 2e-6
 
