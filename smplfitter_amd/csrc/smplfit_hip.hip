@@ -28,6 +28,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <type_traits>
 
 #include "../../include/smplfit.h"
 #include "sf_stages.h"
@@ -268,6 +269,7 @@ struct Tuning {
   int gemm_nchunk = 0;     // SMPLFIT_GEMM_NCHUNK: column-tile chunks of the split-bf16 GEMM (0 = automatic)
   int gemm_lds_kb = 0;     // SMPLFIT_GEMM_LDS_KB: LDS request of the fp32 A-stationary GEMM (occupancy experiments)
   int lpt = 1;             // SMPLFIT_LPT=0: vertex groups launched in table order (read at smplfit_create)
+  bool gemm_tile256 = true;  // SMPLFIT_GEMM_TILE=128: the 256 x 128 workgroup tile of the tiled split-bf16 GEMM (SMPL-X)
   int bm_lds_kb = 0;       // SMPLFIT_BM_LDS_KB: LDS request of the two batch-major vertex passes padded to this (54: three
                            // workgroups per CU instead of four, which leaves registers / LDS for another chunk's small kernels)
 };
@@ -284,6 +286,7 @@ void load_tuning() {
   if (const char* e = env("SMPLFIT_GEMM_NCHUNK")) t.gemm_nchunk = std::max(1, atoi(e));
   if (const char* e = env("SMPLFIT_GEMM_LDS_KB")) t.gemm_lds_kb = atoi(e);
   if (const char* e = env("SMPLFIT_LPT")) t.lpt = atoi(e);
+  if (const char* e = env("SMPLFIT_GEMM_TILE")) t.gemm_tile256 = atoi(e) != 128;
   if (const char* e = env("SMPLFIT_BM_LDS_KB")) t.bm_lds_kb = std::min(std::max(atoi(e), 0), 64);
   g_tune = t;
 }
@@ -527,6 +530,18 @@ int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, b
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_posedirs_gemm_bf16x3_tiled),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
+    if constexpr (kGemm3) {
+      if (nt128 % 2 == 0 && tune().gemm_tile256) {  // 256 x 256 workgroup tiles (k_posedirs_gemm_bf16x3_tiled2)
+        static std::once_flag once2[16];
+        std::call_once(once2[dev_id & 15], [] {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_posedirs_gemm_bf16x3_tiled2),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        });
+        hipLaunchKernelGGL(k_posedirs_gemm_bf16x3_tiled2, dim3(8 * ((mt + 7) / 8) * (nt128 / 2)), dim3(512),
+                           (size_t)2 * kTg2Stage, st, aimg, d.pdB2, ws.vpT, N, Mp, mt, d.kc32, sf::rp_pos(d.P, d.Kp) / 16);
+        return 0;
+      }
+    }
     hipLaunchKernelGGL(k_posedirs_gemm_bf16x3_tiled, dim3(8 * ((mt + 7) / 8) * nt128), dim3(512), (size_t)2 * kTgStage, st,
                        aimg, d.pdB2, ws.vpT, N, Mp, mt, d.kc32, sf::rp_pos(d.P, d.Kp) / 16);
     return 0;
