@@ -618,16 +618,14 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
 }
 
 
-// k-step images of posedirs for k_posedirs_gemm_bf16x3_tiled (models with Kp != 208, three-product form): 63 MB for
-// SMPL-X, so they are built only for a handle that uploads to a device, not by the host-only table builds of the tests.
-// Per 128-column tile: 2 ceil(Kp / 32) steps of [plane hi | plane mid][128 columns][32 B: the two k-octets, swapped on columns
-// with bit 3 set], then the low plane of the bias row's k-step.
+// Stage images of posedirs for k_posedirs_gemm_bf16x3_tiled (models with Kp != 208): 94 MB for SMPL-X, so they
+// are built only for a handle that uploads to a device, not by the host-only table builds of the tests.
 void build_tiled_gemm_images(HostTables& t) {
   const int Vp = t.Vp;
   t.pdB2.clear();
   t.kc32 = 0;
-  if (kGemm3 && t.Kp != 208 && (3 * Vp) % 128 == 0) {
-    const int N = 3 * Vp, Kp = t.Kp, nt128 = N / 128, ks16 = 2 * ((Kp + 31) / 32), bias_step = ((t.P & 1) * (Kp / 2) + (t.P >> 1)) / 16;  // sf::rp_pos(P) / 16
+  if (kGemm3 && t.Kp != 208 && (3 * Vp) % 256 == 0) {  // (the kernel is the three-product form, on 256-column tiles)
+    const int N = 3 * Vp, Kp = t.Kp, nt128 = N / 128, kc32 = (Kp + 31) / 32;
     auto bf16_rne = [](float x) -> uint16_t {
       uint32_t u;
       std::memcpy(&u, &x, 4);
@@ -640,10 +638,9 @@ void build_tiled_gemm_images(HostTables& t) {
       std::memcpy(&f, &u, 4);
       return f;
     };
-    t.kc32 = ks16 / 2;  // (the kernel takes its k-steps in pairs: K padded to a multiple of 32 with zero steps)
-    const size_t plane = (size_t)128 * 16;                    // elements of one plane of a step
-    const size_t tile = (size_t)ks16 * 2 * plane + plane;     // ... of a column tile (steps, then the bias step's low plane)
-    t.pdB2.assign((size_t)nt128 * tile, 0);
+    t.kc32 = kc32;
+    const size_t plane = (size_t)128 * 32;  // elements of one plane of a stage
+    t.pdB2.assign((size_t)nt128 * kc32 * 3 * plane, 0);
     for (int nt = 0; nt < nt128; ++nt)
       for (int n = 0; n < 128; ++n)
         for (int k = 0; k < Kp; ++k) {
@@ -652,12 +649,12 @@ void build_tiled_gemm_images(HostTables& t) {
           const uint16_t h = bf16_rne(x);
           const float r1 = x - bf16_f32(h);
           const uint16_t m = bf16_rne(r1);
-          const int s = k / 16, kk = k % 16, slot = (kk >> 3) ^ ((n >> 3) & 1);
-          const size_t in_plane = (size_t)n * 16 + slot * 8 + (kk & 7);
-          const size_t base = (size_t)nt * tile + (size_t)s * 2 * plane + in_plane;
+          const uint16_t l = bf16_rne(r1 - bf16_f32(m));
+          const int kc = k / 32, kk = k % 32, slot = (kk >> 3) ^ ((n >> 2) & 3);
+          const size_t base = ((size_t)nt * kc32 + kc) * 3 * plane + (size_t)n * 32 + slot * 8 + (kk & 7);
           t.pdB2[base] = h;
           t.pdB2[base + plane] = m;
-          if (s == bias_step) t.pdB2[(size_t)nt * tile + (size_t)ks16 * 2 * plane + in_plane] = bf16_rne(r1 - bf16_f32(m));
+          t.pdB2[base + 2 * plane] = l;
         }
   }
 }

@@ -98,11 +98,11 @@ struct HostTables {
   // three products per k-step (kGemm3) the lo plane is kept for the LAST k-step only (the bias row's: [32 n][2 slots][8 k],
   // slot = (k / 8) & 1), 27 KB per tile instead of 39.  The tile image is copied to LDS verbatim.
   std::vector<uint16_t> pdB;
-  // split-bf16 k-step images of posedirs for the tiled GEMM (Kp != 208, e.g. SMPL-X; three-product form only): per
-  // 128-column tile 2 ceil(Kp / 32) steps of two planes [128 n][2 slots][8 k] (8 KB), slot = (k >> 3) ^ ((n >> 3) & 1), then the
-  // low plane of the bias row's k-step (4 KB)
+  // split-bf16 stage images of posedirs for the tiled GEMM (Kp != 208, e.g. SMPL-X): per 128-column tile and
+  // 32-k stage three planes [128 n][4 slots][8 k] (24 KB), slot = (k >> 3) ^ ((n >> 2) & 3); K padded to kc32 * 32
+  // (with three products per k-step the kernel copies the third plane for the bias row's stage only)
   std::vector<uint16_t> pdB2;
-  int kc32 = 0;  // ceil(Kp / 32) when pdB2 is built, else 0
+  int kc32 = 0;  // stages of 32 k
   // per-vertex constants packed per 64-vertex tile for cooperative staging through LDS:
   // cstride() floats per vertex = [shapedirs s-major (s*3+c), 3*S | KW weights | KW/4 index words | pad]
   std::vector<float> cpackA;    // (Vp/64, 64, cstride) dense tiles of sorted slots  (shape accumulate)

@@ -211,8 +211,8 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w, bool fwd_
   ws.tvs = (float*)take((size_t)B * 3 * Vp * 4);
   ws.vws = (float*)take((size_t)B * Vp * 4);
   // instance-major GEMM output; on the batch-major path of a model with Kp != 208 it holds the split feature
-  // images of the tiled GEMM instead (k_split_features: 16 KB per 256-instance tile and k-step) (kTgStepA)
-  ws.vposed = (float*)take(fwd_only ? (t.Kp != 208 ? (Mp + 255) / 256 * (size_t)((t.Kp + 31) / 32) * ((size_t)2 * 16384) : 0)
+  // images of the tiled GEMM instead (k_split_features: 32 KB per 256-instance tile and 32-k stage)
+  ws.vposed = (float*)take(fwd_only ? (t.Kp != 208 ? (Mp + 255) / 256 * (size_t)((t.Kp + 31) / 32) * ((sf::kGemm3 ? 2 : 3) * 256 * 64) : 0)
                                     : Mp * 3 * Vp * 4, true);
   ws.rp = (float*)take(Mp * t.Kp * 4, true);
   ws.mean = (float*)take((size_t)B * 3 * 4);
@@ -518,9 +518,9 @@ int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, b
   }
   if (d.Kp != 208 && transposed && d.kc32 > 0 && gemm_bf16x3() && d.gemm_exclusive) {
     // tiled split-bf16 GEMM (SMPL-X): the feature images go to ws.vposed, which the batch-major path does not use
-    const int mt = (Mp + 255) / 256, nt128 = N / 128, ks16 = 2 * d.kc32;
+    const int mt = (Mp + 255) / 256, nt256 = N / 256;
     uint16_t* aimg = reinterpret_cast<uint16_t*>(ws.vposed);
-    hipLaunchKernelGGL(k_split_features, dim3(mt, d.kc32), dim3(256), 0, st, ws.rp, aimg, Mp, d.Kp, ks16);
+    hipLaunchKernelGGL(k_split_features, dim3(mt, d.kc32), dim3(256), 0, st, ws.rp, aimg, Mp, d.Kp, d.kc32);
     static std::once_flag once[16];
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
@@ -528,9 +528,8 @@ int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, b
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_posedirs_gemm_bf16x3_tiled),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    const size_t lds = std::max<size_t>(kTgLds, std::min(160, tune().gemm_lds_kb) * (size_t)1024);  // (> 80 KB: one per CU)
-    hipLaunchKernelGGL(k_posedirs_gemm_bf16x3_tiled, dim3(8 * ((mt + 7) / 8) * nt128), dim3(256), lds, st, aimg,
-                       d.pdB2, ws.vpT, N, Mp, mt, ks16, sf::rp_pos(d.P, d.Kp) / 16);
+    hipLaunchKernelGGL(k_posedirs_gemm_bf16x3_tiled, dim3(8 * ((mt + 7) / 8) * nt256), dim3(512), (size_t)2 * kTg2Stage, st,
+                       aimg, d.pdB2, ws.vpT, N, Mp, mt, d.kc32, sf::rp_pos(d.P, d.Kp) / 16);
     return 0;
   }
   if (d.Kp == 208) {  // SMPL (J = 24): A-stationary kernel, 104 A registers per lane
@@ -1122,7 +1121,7 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
     *out = h;
     return SMPLFIT_OK;
   }
-  // k-step images of the tiled split-bf16 GEMM (63 MB for SMPL-X): only for a model whose fits can take the
+  // stage images of the tiled split-bf16 GEMM (94 MB for SMPL-X): only for a model whose fits can take the
   // batch-major path (the only launches that read them; the structural part of bm_applies)
   if (h->t.KW == 4 && (h->t.S == 10 || h->t.S == 11) && h->t.wsum_dev <= 1e-5f)
     sf::build_tiled_gemm_images(h->t);

@@ -343,19 +343,20 @@ def test_workspace_guards(name, model_root, golden, dev):
             assert torch.equal(out['zero'][k], out['nan'][k]), k
 
 
-def test_neighbour_stress(model_root, golden, dev):
-    """The split-bf16 GEMM must never share a CU with another kernel (k_posedirs_gemm_bf16x3, "exclusive CU"): beside
-    its LDS-fed bf16 MFMAs, other kernels' waves were seen to read wrong lanes.  The guard is an occupancy one (256
-    VGPRs x 8 waves), so it is stressed: 200 default two-chunk fits at B = 4096 while a SECOND handle fits on its own
-    stream from another thread and torch streams elementwise kernels on a third — every one of the 200 results must
-    be bit-identical to the first.  Also checks the kernel really allocates the whole register file."""
+@pytest.mark.parametrize('name,B,reps', [('smpl', 4096, 200), ('smplx', 2048, 60)])
+def test_neighbour_stress(name, B, reps, model_root, golden, dev):
+    """The split-bf16 GEMMs must never share a CU with another kernel (k_posedirs_gemm_bf16x3 and, for the SMPL-X-shaped
+    model, k_posedirs_gemm_bf16x3_tiled: "exclusive CU"): beside their LDS-fed bf16 MFMAs, other kernels' waves were
+    seen to read wrong lanes.  The guard is an occupancy one (256 VGPRs x 8 waves), so it is stressed: default two-chunk
+    fits (200 at B = 4096 / 60 at 2048) while a SECOND handle fits on its own stream from another thread and torch
+    streams elementwise kernels on a third — every result must be bit-identical to the first.  Also checks the kernels
+    really allocate the whole register file."""
     import threading
 
     from smplfitter_amd.pt import BodyFitter, BodyModel
 
-    g = golden('smpl')
-    m, f = get_model(model_root, 'smpl', g, dev)
-    B = 4096
+    g = golden(name)
+    m, f = get_model(model_root, name, g, dev)
     tv, tj = make_targets(m, B, 42, dev)
     h = m._native(dev)
     assert h.info.gemm_vgprs >= 256, h.info.gemm_vgprs  # the occupancy guard: 8 waves x 256 registers = one CU
@@ -365,9 +366,10 @@ def test_neighbour_stress(model_root, golden, dev):
     ref = {k: ref[k].clone() for k in ('pose_rotvecs', 'shape_betas', 'trans')}
     torch.cuda.synchronize()
     # foreign work: another handle of the same model (its own constants, streams, workspace) + torch elementwise
-    m2 = BodyModel('smpl', 'neutral', model_root=f'{model_root}/smpl', num_betas=10, device=dev)
+    m2 = BodyModel(name, 'neutral', model_root=f'{model_root}/{name}', num_betas=10, device=dev)
     f2 = BodyFitter(m2)
-    tv2, tj2 = make_targets(m2, 2048, 7, dev)
+    B2 = B // 2
+    tv2, tj2 = make_targets(m2, B2, 7, dev)
     stop = threading.Event()
     errors = []
 
@@ -375,7 +377,7 @@ def test_neighbour_stress(model_root, golden, dev):
         try:
             s = torch.cuda.Stream(device=dev)
             with torch.cuda.stream(s):
-                ws2 = torch.empty(m2._native(dev).workspace_bytes(2048), dtype=torch.uint8, device=dev)
+                ws2 = torch.empty(m2._native(dev).workspace_bytes(B2), dtype=torch.uint8, device=dev)
                 while not stop.is_set():
                     f2.fit(tv2, tj2, num_iter=2, beta_regularizer=1.0, _workspace=ws2)
                     s.synchronize()
@@ -399,7 +401,7 @@ def test_neighbour_stress(model_root, golden, dev):
         th.start()
     bad = torch.zeros((), dtype=torch.int64, device=dev)
     try:
-        for _ in range(200):
+        for _ in range(reps):
             r = f.fit(tv, tj, **kw)
             for k, v in ref.items():
                 bad += (r[k] != v).sum()
