@@ -10,10 +10,12 @@
 // several iterations are then issued together instead of one memory latency per iteration (the
 // accumulation order is unchanged)
 #define SF_UNROLL(n) _Pragma(SF_STR_(unroll n))
+#define SF_UNROLL_FULL _Pragma("unroll")
 #define SF_STR_(x) #x
 #else
 #define SF_HD inline
 #define SF_UNROLL(n)
+#define SF_UNROLL_FULL
 #endif
 
 // Scheduling fence for the device compiler: stops it from hoisting the LDS loads of later phases

@@ -98,10 +98,124 @@ SF_HD JointScratch carve_joint_scratch(float* base, int J, int S, int kind) {
   s.pos = s.aux + J * 3;
   return s;
 }
-// solve stage scratch: (NE+1) + S*S + S doubles, then S+3 floats
-SF_HD int solve_scratch_floats(int S) { return 2 * (ne_size(S) + 1 + S * S + S) + ((S + 3 + 3) / 4 * 4); }
+// solve stage scratch: (NE+1) + S*S + S + kSolveParts*S doubles, then S+3 floats
+constexpr int kSolveParts = 6;  // partial sums of the T' part of Jac^T b (see solve_stage)
+SF_HD int solve_scratch_floats(int S) {
+  return 2 * (ne_size(S) + 1 + S * S + S + kSolveParts * S) + ((S + 3 + 3) / 4 * 4);
+}
 
 #define SF_FOR(i, count) for (int i = cx.lane; i < (count); i += cx.n)
+// timing experiments (tools/stage_stamps.sh, -DSMPLFIT_STAGE_STAMPS): cycle stamps at the sync points of the joint stages
+#ifdef SMPLFIT_STAGE_STAMPS
+#define SF_STAMP(k) cx.stamp(k)
+#else
+#define SF_STAMP(k)
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// Joint block of the normal equations (+ the closed-form vertex SA) with a lane per JOINT: every lane accumulates the
+// terms of its joints' three rows in registers, then one wave sum per entry (cx.sum_to_last: the total on the last lane,
+// which stores it).  The entry-per-lane form in joint_stage below walks the 3 J rows serially in every lane, once per
+// branch the wave's lanes diverge into: 37 k of the 93 k cycles of k_joint_stage for SMPL, 78 k of 160 k for the
+// SMPL-X-shaped model (tools/stage_stamps.sh); this form: see DESIGN.md.  Two phases (the Gramian, then everything
+// else) keep the live accumulators under the registers of four waves per SIMD.  Same sums as the generic form; on the
+// device the order of the additions differs (a tree over the lanes instead of one chain).
+// ---------------------------------------------------------------------------------------------
+template <int S, class Ctx>
+SF_HD void joint_gram_by_joint(Ctx& cx, const JointTabs& tb, const JointScratch& sh, const float* jw, bool joint_block,
+                               bool weighted, bool closed_form, float* gramj_out) {
+  constexpr int S1 = S + 1, NG = ne_ng(S), NE = ne_size(S);
+  const int J = tb.J;
+  const bool last = cx.lane == cx.n - 1;
+  {
+    // row i of the Gramian is kept from column i & ~1 (an even column) to SE: the products of a row then pair up with
+    // ALIGNED pairs of the joint row's values (packed fp32 without shuffled copies of them); the extra entries (column
+    // i - 1 of the odd rows, the zero padding of an odd S) are computed and not used
+    constexpr int SE = (S + 1) & ~1;
+    float g[S][SE];
+    SF_UNROLL_FULL
+    for (int i = 0; i < S; ++i)
+      SF_UNROLL_FULL
+      for (int k = i & ~1; k < SE; ++k) g[i][k] = 0.f;
+    if (joint_block) {
+      for (int j = cx.lane; j < J; j += cx.n) {
+        const float w = weighted ? jw[j] : 1.0f;
+        SF_UNROLL_FULL
+        for (int c = 0; c < 3; ++c) {
+          const float* pr = sh.P + (j * 3 + c) * S1 + 1;
+          float p[SE];
+          SF_UNROLL_FULL
+          for (int i = 0; i < SE; ++i) p[i] = i < S ? pr[i] : 0.f;
+          SF_UNROLL_FULL
+          for (int i = 0; i < S; ++i) {
+            const float wp = w * p[i];
+            SF_UNROLL_FULL
+            for (int k = i & ~1; k < SE; ++k) g[i][k] += wp * p[k];
+          }
+          SF_SCHED_FENCE();  // (one row's reads at a time: registers)
+        }
+      }
+    }
+    SF_UNROLL_FULL
+    for (int i = 0; i < S; ++i)
+      SF_UNROLL_FULL
+      for (int i2 = i; i2 < S; ++i2) {
+        const float t = cx.sum_to_last(g[i][i2]);
+        if (last) gramj_out[ne_g(S, i, i2)] = t;
+      }
+  }
+  cx.sync();  // (also keeps the second phase's reads out of the first phase's registers)
+  {
+    float r[S], sa[3][S], sb[3] = {0.f, 0.f, 0.f}, W = 0.f;
+    SF_UNROLL_FULL
+    for (int i = 0; i < S; ++i) r[i] = sa[0][i] = sa[1][i] = sa[2][i] = 0.f;
+    for (int j = cx.lane; j < J; j += cx.n) {
+      const float w = weighted ? jw[j] : 1.0f;
+      const float cw = closed_form ? tb.cw_joint[j] : 0.f;
+      SF_UNROLL_FULL
+      for (int c = 0; c < 3; ++c) {
+        SF_SCHED_FENCE();
+        if (joint_block) {
+          const float* pr = sh.P + (j * 3 + c) * S1;
+          const float d = sh.tj[j * 3 + c] - pr[0];
+          SF_UNROLL_FULL
+          for (int i = 0; i < S; ++i) {
+            const float wp = w * pr[1 + i];
+            r[i] += wp * d;
+            sa[c][i] += wp;
+          }
+          sb[c] += d * w;
+        }
+        if (closed_form) {  // vertex-block SA with unit weights, sum_v Jac_v[c][i] = sum_j (G_j CS_j)[c][i] + cw_j T'_j[c][i]
+          const float* Gj = sh.G + j * 9 + c * 3;
+          const float* cs = tb.cs_joint + j * 3 * S;
+          const float* tr = sh.T + (j * 3 + c) * S1 + 1;
+          SF_UNROLL_FULL
+          for (int i = 0; i < S; ++i) sa[c][i] += (Gj[0] * cs[i] + Gj[1] * cs[S + i] + Gj[2] * cs[2 * S + i]) + cw * tr[i];
+        }
+        SF_SCHED_FENCE();
+      }
+      if (joint_block) W += w;
+    }
+    SF_UNROLL_FULL
+    for (int i = 0; i < S; ++i) {
+      const float t = cx.sum_to_last(r[i]);
+      if (last) gramj_out[NG + i] = t;
+    }
+    SF_UNROLL_FULL
+    for (int c = 0; c < 3; ++c) {
+      SF_UNROLL_FULL
+      for (int i = 0; i < S; ++i) {
+        const float t = cx.sum_to_last(sa[c][i]);
+        if (last) gramj_out[NG + S + c * S + i] = t;
+      }
+      const float t = cx.sum_to_last(sb[c]);
+      if (last) gramj_out[NG + 4 * S + c] = t;
+    }
+    const float t = cx.sum_to_last(W);
+    if (last) gramj_out[NE] = t;
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 // Stage J — part rotations (+ optional shape-solve prologue).
@@ -118,6 +232,7 @@ SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
                        bool joint_block_weighted, bool vertex_sa_closed_form, float* Gout,
                        float* rp_out, float* jd_out, float* pext_out, float* gramj_out) {
   const int J = tb.J, S = tb.S, S1 = S + 1;
+  SF_STAMP(0);
   SF_FOR(k, J * 3) {
     sh.tj[k] = tjc[k];
     sh.rj[k] = rj_in ? rj_in[k] : 0.f;
@@ -181,6 +296,7 @@ SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
     for (int k = 0; k < 9; ++k) sh.R[j * 9 + k] = R[k];
   }
   cx.sync();
+  SF_STAMP(1);
   SF_FOR(j, J) {  // toes take the feet; compose with the previous rotations (:422-433)
     if (!fit_rotations) break;
     const int src = tb.toe_src[j] >= 0 ? tb.toe_src[j] : j;
@@ -196,6 +312,7 @@ SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
     }
   }
   cx.sync();
+  SF_STAMP(2);
   if (!do_prologue) return;
 
   // relative rotations -> pose feature (:869-876, :913); root row of P (:889-891)
@@ -210,6 +327,7 @@ SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
   SF_FOR(k, tb.Kp - tb.P) rp_out[rp_pos(tb.P + k, tb.Kp)] = k == 0 ? 1.f : 0.f;
   SF_FOR(k, 3 * S1) sh.P[k] = tb.j_ext[k];
   cx.sync();
+  SF_STAMP(3);
   // level-batched FK of positions and their beta-Jacobian (:892-907)
   for (int lv = 0; lv < tb.num_levels; ++lv) {
     const int l0 = tb.fk_level_start[lv], nl = tb.fk_level_start[lv + 1] - l0;
@@ -224,6 +342,7 @@ SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
     }
     cx.sync();
   }
+  SF_STAMP(4);
   // T = P - G J_ext (:909-911); joint block for the vertex kernels; P for the solve stage
   const int stride = jd_stride(S), row = jd_row(S);
   SF_FOR(idx, J * S1) {
@@ -250,6 +369,15 @@ SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
   // joint block of the normal equations, fp32 sums (:1051-1053, _gram_block :1598-1625)
   const int NG = ne_ng(S), NE = ne_size(S);
   cx.sync();
+  SF_STAMP(5);
+  if (S == 10 || S == 11) {  // (the shapes the batch-major path serves; more unknowns: the Gramian does not fit registers)
+    if (S == 10)
+      joint_gram_by_joint<10>(cx, tb, sh, jw, joint_block, joint_block_weighted, vertex_sa_closed_form, gramj_out);
+    else
+      joint_gram_by_joint<11>(cx, tb, sh, jw, joint_block, joint_block_weighted, vertex_sa_closed_form, gramj_out);
+    SF_STAMP(6);
+    return;
+  }
   SF_FOR(e, NE + 1) {
     float acc = 0.f;
     if (vertex_sa_closed_form && e >= NG + S && e < NG + 4 * S) {
@@ -305,6 +433,7 @@ SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
     }
     gramj_out[e] = acc;
   }
+  SF_STAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -340,16 +469,29 @@ SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const doubl
   double* sum = reinterpret_cast<double*>(scratch);  // NE+1   (scratch is 8-byte aligned)
   double* M = sum + NE + 1;                          // S*S (lower triangle used)
   double* x = M + S * S;                             // S
-  float* aux = reinterpret_cast<float*>(x + S);      // S+3
+  double* r2p = x + S;                               // kSolveParts * S
+  float* aux = reinterpret_cast<float*>(r2p + kSolveParts * S);  // S+3
+  if (mb) {
+    // pair-Gram form: the residual kernel delivers r1 = sum_v S_v^T (Rt_v^T b_v) and the per-joint residual moments
+    // mb_j = sum_v w_vj b_v; the T' part of Jac^T b is sum_j T'_j^T mb_j.  kSolveParts lanes per unknown sum a run of
+    // joints each (one dependent memory round trip per joint of the run instead of one per joint of the model: the
+    // rows live in global memory), in a fixed order on every target.
+    const int stride = jd_stride(S), row = jd_row(S), run = (J + kSolveParts - 1) / kSolveParts;
+    SF_FOR(t, kSolveParts * S) {
+      const int i = t % S, part = t / S;
+      const int j1 = (part + 1) * run < J ? (part + 1) * run : J;
+      double r2 = 0.0;
+      for (int j = part * run; j < j1; ++j)
+        for (int c = 0; c < 3; ++c) r2 += (double)jd[j * stride + 12 + c * row + i] * (double)mb[j * 3 + c];
+      r2p[t] = r2;
+    }
+    cx.sync();
+  }
   SF_FOR(e, NE + 1) {
     double v = gramv[e] + (double)gramj[e];
     if (mb && e >= NG && e < NG + S) {
-      // pair-Gram form: the residual kernel delivers r1 = sum_v S_v^T (Rt_v^T b_v) and the per-joint
-      // residual moments mb_j = sum_v w_vj b_v; the T' part of Jac^T b is sum_j T'_j^T mb_j
-      const int i = e - NG, stride = jd_stride(S), row = jd_row(S);
       double r2 = 0.0;
-      for (int j = 0; j < J; ++j)
-        for (int c = 0; c < 3; ++c) r2 += (double)jd[j * stride + 12 + c * row + i] * (double)mb[j * 3 + c];
+      for (int part = 0; part < kSolveParts; ++part) r2 += r2p[part * S + (e - NG)];
       v += r2;
     }
     sum[e] = v;

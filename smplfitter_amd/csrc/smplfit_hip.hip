@@ -127,11 +127,6 @@ struct smplfit_convert_plan {
 
 namespace {
 
-struct DevCtx {
-  int lane, n;
-  __device__ __forceinline__ void sync() const { __syncthreads(); }
-};
-
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -153,6 +148,17 @@ __device__ __forceinline__ float wave_sum_last(float v) {
   v = dpp_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave total
   return v;
 }
+
+// the per-instance stages of sf_stages.h run with one wave per instance: lane / n / sync / sum_to_last
+struct DevCtx {
+  int lane, n;
+  __device__ __forceinline__ void sync() const { __syncthreads(); }
+  __device__ __forceinline__ float sum_to_last(float v) const { return wave_sum_last(v); }  // (n == 64: one wave)
+#ifdef SMPLFIT_STAGE_STAMPS
+  long long t[12] = {};
+  __device__ __forceinline__ void stamp(int k) { t[k] = __builtin_readcyclecounter(); }
+#endif
+};
 
 // Per-call workspace carve (device pointers).
 struct Workspace {

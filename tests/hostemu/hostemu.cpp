@@ -20,6 +20,7 @@ namespace {
 struct HostCtx {
   int lane = 0, n = 1;
   void sync() const {}
+  float sum_to_last(float v) const { return v; }  // (one lane: the partial sum is the sum)
 };
 
 sf::JointTabs make_tabs(const sf::HostTables& t) {
