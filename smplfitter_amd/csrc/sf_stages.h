@@ -471,6 +471,7 @@ SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const doubl
   double* x = M + S * S;                             // S
   double* r2p = x + S;                               // kSolveParts * S
   float* aux = reinterpret_cast<float*>(r2p + kSolveParts * S);  // S+3
+  SF_STAMP(0);
   if (mb) {
     // pair-Gram form: the residual kernel delivers r1 = sum_v S_v^T (Rt_v^T b_v) and the per-joint residual moments
     // mb_j = sum_v w_vj b_v; the T' part of Jac^T b is sum_j T'_j^T mb_j.  kSolveParts lanes per unknown sum a run of
@@ -497,6 +498,7 @@ SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const doubl
     sum[e] = v;
   }
   cx.sync();
+  SF_STAMP(1);
   double W = sum[NE];
   if (W == 0.0) W = 1.0;  // w_sum_safe (:1060)
   const double* SA = sum + NG + S;
@@ -528,6 +530,7 @@ SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const doubl
     SF_FOR(i, S) x[i] = cen[S * S + i];
     cx.sync();
   }
+  SF_STAMP(2);
   // in-place Cholesky M = L L^T (:1083), column by column
   for (int k = 0; k < S; ++k) {
     if (cx.lane == 0) M[k * S + k] = sqrt(M[k * S + k]);
@@ -540,6 +543,7 @@ SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const doubl
     }
     cx.sync();
   }
+  SF_STAMP(3);
   if (cx.lane == 0) {  // forward / back substitution (:1084)
     for (int i = 0; i < S; ++i) {
       double v = x[i];
@@ -553,6 +557,7 @@ SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const doubl
     }
   }
   cx.sync();
+  SF_STAMP(4);
   // translation (:1086-1088) and outputs, cast to fp32 (:1088-1089)
   float* betaf = aux;       // S
   float* transf = aux + S;  // 3
@@ -581,6 +586,7 @@ SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const doubl
     jb_out[j * 4 + c] = jd[j * stride + 9 + c] + tb0;
     if (jbT_out) jbT_out[(j * 4 + c) * 64] = jd[j * stride + 9 + c] + tb0;
   }
+  SF_STAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------------
