@@ -417,6 +417,14 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
       t.bone_ext[(size_t)j * 3 * S1 + k] =
           t.j_ext[(size_t)j * 3 * S1 + k] - t.j_ext[(size_t)t.parents[j] * 3 * S1 + k];
 
+  t.fk_jp.resize(t.fk_js.size());
+  t.bone_lv.assign(t.fk_js.size() * 3 * S1, 0.f);
+  for (size_t q = 0; q < t.fk_js.size(); ++q) {
+    const int j = t.fk_js[q];
+    t.fk_jp[q] = j | (t.parents[j] << 16);
+    for (int k = 0; k < 3 * S1; ++k) t.bone_lv[q * 3 * S1 + k] = t.bone_ext[(size_t)j * 3 * S1 + k];
+  }
+
   // template-pass part sums of the reference side (s_a, s_w of _part_sums with a = default mesh)
   t.sa0.assign((size_t)J * 3, 0.f);
   t.sw0.assign(J, 0.f);

@@ -111,6 +111,10 @@ struct HostTables {
   // per-joint constants
   std::vector<float> j_ext;     // (J,3,S+1)  [J_template | J_shapedirs]
   std::vector<float> bone_ext;  // (J,3,S+1)  j_ext - j_ext[parent] (root: j_ext - j_ext[0] = 0)
+  // the level FK of the joint stage without dependent table reads: per position of fk_js the packed (joint | parent << 16)
+  // and a copy of the joint's bone_ext rows in that order
+  std::vector<int32_t> fk_jp;
+  std::vector<float> bone_lv;   // (len(fk_js),3,S+1)
   std::vector<float> sa0;       // (J,3) sum of default-mesh vertices per part (template pass)
   std::vector<float> sw0;       // (J)   vertex count per part
   std::vector<float> cs_joint;  // (J,3,S) sum_v w_vj shapedirs_v  (closed-form SA of the vertex block)

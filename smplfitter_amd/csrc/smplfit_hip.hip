@@ -1264,6 +1264,8 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
   up(t.adj_parts, &jt.adj_parts);
   up(t.j_ext, &jt.j_ext);
   up(t.bone_ext, &jt.bone_ext);
+  up(t.fk_jp, &jt.fk_jp);
+  up(t.bone_lv, &jt.bone_lv);
   up(t.cs_joint, &jt.cs_joint);
   up(t.cw_joint, &jt.cw_joint);
   jt.np = (int)t.pair_c3.size();

@@ -34,6 +34,7 @@ sf::JointTabs make_tabs(const sf::HostTables& t) {
   jt.cas_flat = t.cas_flat.data(); jt.part_type = t.part_type.data(); jt.toe_src = t.toe_src.data();
   jt.adj_level_start = t.adj_level_start.data(); jt.adj_parts = t.adj_parts.data();
   jt.j_ext = t.j_ext.data(); jt.bone_ext = t.bone_ext.data();
+  jt.fk_jp = t.fk_jp.data(); jt.bone_lv = t.bone_lv.data();
   jt.cs_joint = t.cs_joint.data(); jt.cw_joint = t.cw_joint.data();
   jt.np = (int)t.pair_c3.size(); jt.pair_j = t.pair_j.data(); jt.pair_c1 = t.pair_c1.data();
   jt.pair_c2 = t.pair_c2.data(); jt.pair_c3 = t.pair_c3.data(); jt.diag_g0 = t.diag_g0.data();
