@@ -63,6 +63,10 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
   // tile when those kernels apply: measured at B = 16384, 1024 vertices 4.58 -> 4.79 M fits/s, 2048
   // vertices 3.10 -> 3.69 M (512: the wave-per-instance kernels stay ahead, 5.85 vs 5.65 M).
   if (t.Vp == V && (S == 10 || S == 11) && V >= 1024) t.Vp += kVertexPad;
+  // models whose pose features do not fit the A-stationary GEMM (more than 24 joints): the tiled split-bf16 GEMM works on
+  // 256-column tiles, so 3 Vp has to be a multiple of 256 (a vertex subset with an odd number of 128-vertex tiles would
+  // otherwise fall back to the fp32 GEMM, three times slower)
+  if (t.P + 1 > 208) t.Vp = round_up(t.Vp, 2 * kVertexPad);
   // at least one padding row: row P of posedirs holds v_template and the matching pose feature is 1, so
   // the GEMM needs no bias operand (and adds the template last, as the reference does, bodyfitter.py:913-916)
   t.Kp = round_up(t.P + 1, kGemmKPad);
