@@ -71,6 +71,10 @@ void smplfit_destroy(smplfit_handle* h);
 
 const char* smplfit_last_error(void);
 const char* smplfit_version(void);
+/* Version of this header's structs and entry points; bumped whenever a struct gains a field or a signature
+ * changes.  A client compares it with the SMPLFIT_ABI_VERSION it was built against before the first call. */
+#define SMPLFIT_ABI_VERSION 4
+int smplfit_abi_version(void);
 
 typedef struct smplfit_info {
   int32_t num_vertices, num_joints, num_betas; /* num_betas excludes the kid unknown */
@@ -97,10 +101,22 @@ enum smplfit_table_id {
   SMPLFIT_TAB_ADJ_FLAG = 5,        /* (J)  1 if refined by the final adjustment                 */
   SMPLFIT_TAB_USED_PART = 6,       /* (J)  1 if the part's vertices enter the part sums         */
   SMPLFIT_TAB_SEGMENTS = 7,        /* (nseg,3) start, count, part                               */
-  SMPLFIT_TAB_VERTEX_GROUPS = 8,   /* (ngroups,5) start, count, part, used, joints: the workgroup
-                                      units of the batch-major vertex kernels                    */
+  SMPLFIT_TAB_VERTEX_PIECES = 8,   /* (npieces,5) start, count, part, used, joints: the pieces of the
+                                      sorted slots the batch-major vertex kernels walk (runs of one
+                                      part with at most four skinning joints)                    */
+  SMPLFIT_TAB_CELL_COUNTS = 9,     /* (4) cells per instance block of the four cell tables below (empty: the
+                                      model has no batch-major tables)                            */
 };
 int smplfit_get_table(const smplfit_handle* h, int table_id, int32_t* dst, size_t cap, size_t* n);
+
+/* Cell tables of the batch-major vertex kernels (test access): `kind` 0 residual pass, 1 part sums over every slot,
+ * 2 over the used parts, 3 over the adjustable parts; `what` 0 piece_start (ncells + 1), 1 piece records
+ * (npieces + 1, 12): count, joints[4], local slots[4], first slot, row closed behind the piece (-1 none), kind 0:
+ * joints of that row | (cell + 1) << 8 behind the last piece of a cell; 2 the rows: part per row (kinds 1-3) or
+ * (nrows, 12) joint of every local slot, -1 unused (kind 0). */
+int smplfit_get_share_table(const smplfit_handle* h, int kind, int what, int32_t* dst, size_t cap, size_t* n);
+/* Cells per wave a launch over `batch` instances picks for `kind` (with the current tuning options). */
+int smplfit_pick_share_mult(const smplfit_handle* h, int kind, int batch);
 
 /* Bytes of device workspace a call on `batch` instances needs (256-byte aligned base). */
 size_t smplfit_workspace_bytes(const smplfit_handle* h, int batch);

@@ -23,10 +23,11 @@ SMPLFIT_ERR_UNSUPPORTED = -2
 SMPLFIT_ERR_WORKSPACE = -3
 SMPLFIT_ERR_HIP = -4
 SMPLFIT_CREATE_HOST_ONLY = 1
+SMPLFIT_ABI_VERSION = 4  # include/smplfit.h; checked against smplfit_abi_version() when the library is loaded
 
 TABLE_IDS = dict(
     part_assignment=0, sort_perm=1, part_type=2, fk_order=3, fk_level_start=4, adj_flag=5,
-    used_part=6, segments=7, vertex_groups=8,
+    used_part=6, segments=7, vertex_pieces=8, cell_counts=9,
 )
 
 # every symbol include/smplfit.h declares
@@ -38,7 +39,8 @@ EXPORTED_SYMBOLS = [
     'smplfit_time_kernel_f32', 'smplfit_primitives_f32', 'smplfit_forward_ex_f32',
     'smplfit_transfer_create', 'smplfit_transfer_destroy', 'smplfit_transfer_f32',
     'smplfit_convert_plan_create', 'smplfit_convert_plan_destroy', 'smplfit_convert_workspace_bytes',
-    'smplfit_convert_f32', 'smplfit_reload_options',
+    'smplfit_convert_f32', 'smplfit_reload_options', 'smplfit_get_share_table', 'smplfit_pick_share_mult',
+    'smplfit_abi_version',
 ]  # fmt: skip
 
 _fp = C.POINTER(C.c_float)
@@ -212,6 +214,18 @@ def load():
     lib.smplfit_convert_f32.restype = i32
     lib.smplfit_reload_options.argtypes = []
     lib.smplfit_reload_options.restype = i32
+    if os.environ.get('SMPLFIT_LIB') and not hasattr(lib, 'smplfit_abi_version'):
+        _lib = lib  # an older build loaded by the A/B tools (tools/ab_fit.py): no version / share-table exports
+        return lib
+    lib.smplfit_abi_version.argtypes = []
+    lib.smplfit_abi_version.restype = i32
+    if lib.smplfit_abi_version() != SMPLFIT_ABI_VERSION:
+        raise ImportError(f'{LIB_PATH} was built for ABI {lib.smplfit_abi_version()}, this package expects '
+                          f'{SMPLFIT_ABI_VERSION}: rebuild it (python -m smplfitter_amd.build --force)')
+    lib.smplfit_get_share_table.argtypes = [vp, i32, i32, _ip, sz, C.POINTER(sz)]
+    lib.smplfit_get_share_table.restype = i32
+    lib.smplfit_pick_share_mult.argtypes = [vp, i32, i32]
+    lib.smplfit_pick_share_mult.restype = i32
     _lib = lib
     return lib
 
@@ -292,6 +306,15 @@ class Handle:
         check(lib.smplfit_get_table(self._h, TABLE_IDS[name], None, 0, C.byref(n)))
         out = np.zeros(n.value, np.int32)
         check(lib.smplfit_get_table(self._h, TABLE_IDS[name], out.ctypes.data_as(_ip), n.value, C.byref(n)))
+        return out
+
+    def share_table(self, kind: int, what: int) -> np.ndarray:
+        """Cell tables of the batch-major vertex kernels (``smplfit_get_share_table``)."""
+        lib = load()
+        n = C.c_size_t()
+        check(lib.smplfit_get_share_table(self._h, kind, what, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.int32)
+        check(lib.smplfit_get_share_table(self._h, kind, what, out.ctypes.data_as(_ip), n.value, C.byref(n)))
         return out
 
     def workspace_bytes(self, batch: int) -> int:

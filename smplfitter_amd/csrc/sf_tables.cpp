@@ -13,6 +13,180 @@ namespace sf {
 
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// ---- share tables of the batch-major vertex kernels (see sf_tables.h) ----
+namespace {
+struct PieceRun {  // a whole or split piece on its way into a share
+  int start, count, part, nj;
+  const int32_t* joints;
+};
+int piece_cost(int count) { return count + (count & 1) + kPieceCost; }
+
+void build_share_table(const HostTables& t, int kind, ShareTable& out) {
+  out = ShareTable();
+  std::vector<PieceRun> dom;
+  long total = 0;
+  for (const auto& p : t.vpieces) {
+    const bool in = kind == kShareLbsUsed ? p.used != 0 : kind == kShareLbsAdj ? t.adj_flag[p.part] != 0 : true;
+    if (!in) continue;
+    dom.push_back({p.start, p.count, p.part, p.nj, p.joints});
+    total += piece_cost(p.count);
+  }
+  // cells of ~75+ steps, a power of two of them (so that the share counts of power-of-two batches fill whole rounds)
+  int ns = 8;
+  while (ns < 256 && (long)ns * 2 * SMPLFIT_CELL_STEPS <= total) ns *= 2;
+  // deal the domain to ns cells of equal cost: whole pieces while they fit, then the head of the next one (an even
+  // number of vertices, so that a split adds no padding step).  Every boundary that splits a piece costs the piece
+  // overhead once more: the budget of a cell counts it for the boundaries still ahead.
+  std::vector<std::vector<PieceRun>> sh;
+  for (;; ns /= 2) {
+    sh.assign(ns, {});
+    size_t pi = 0;
+    PieceRun cur{};
+    bool have = false;
+    long work = total;  // cost of the pieces (and the remainder of a split one) not dealt yet
+    for (int k = 0; k < ns; ++k) {
+      long budget = (work + (long)kPieceCost * (ns - 1 - k) + (ns - k) - 1) / (ns - k);
+      while (have || pi < dom.size()) {
+        if (!have) {
+          cur = dom[pi++];
+          have = true;
+        }
+        const int c = piece_cost(cur.count);
+        if (c <= budget || k + 1 == ns) {
+          sh[k].push_back(cur);
+          budget -= c;
+          work -= c;
+          have = false;
+          continue;
+        }
+        const int x = (int)((budget - kPieceCost) & ~1L);  // vertices of the head
+        if (x >= 2 && x < cur.count) {
+          PieceRun head = cur;
+          head.count = x;
+          sh[k].push_back(head);
+          work -= x;
+          cur.start += x;
+          cur.count -= x;
+        } else if (sh[k].empty()) {  // (a cell is never left empty)
+          sh[k].push_back(cur);
+          work -= c;
+          have = false;
+        }
+        break;
+      }
+    }
+    bool empty = false;
+    for (int k = 0; k < ns; ++k) empty |= sh[k].empty();
+    if (!empty || ns <= 8) break;
+  }
+  out.ncells = ns;
+  // records, rows
+  out.piece_start.assign(1, 0);
+  int row = 0;
+  for (int k = 0; k < ns; ++k) {
+    const auto& ps = sh[k];
+    int cost = 0;
+    if (kind == kShareResidual) {
+      // segments: runs of pieces whose joints number at most kGroupJoints together
+      size_t a = 0;
+      while (a < ps.size()) {
+        int slots[kMaxJoints];
+        for (int j = 0; j < kMaxJoints; ++j) slots[j] = -1;
+        int nq = 0;
+        size_t b = a;
+        std::vector<int> order;
+        while (b < ps.size()) {
+          int add = 0;
+          for (int q = 0; q < ps[b].nj; ++q)
+            if (slots[ps[b].joints[q]] < 0) {
+              bool dup = false;
+              for (int q2 = 0; q2 < q; ++q2) dup |= ps[b].joints[q2] == ps[b].joints[q];
+              if (!dup) ++add;
+            }
+          if (nq + add > kGroupJoints) break;
+          for (int q = 0; q < ps[b].nj; ++q)
+            if (slots[ps[b].joints[q]] < 0) {
+              slots[ps[b].joints[q]] = nq++;
+              order.push_back(ps[b].joints[q]);
+            }
+          ++b;
+        }
+        for (size_t i = a; i < b; ++i) {
+          int32_t rec[kPieceRec] = {0};
+          rec[0] = ps[i].count;
+          for (int q = 0; q < 4; ++q) {
+            rec[1 + q] = ps[i].joints[q];
+            rec[5 + q] = slots[ps[i].joints[q]];
+          }
+          rec[9] = ps[i].start;
+          rec[10] = i + 1 == b ? row : -1;
+          rec[11] = (i + 1 == b ? nq : 0) | (i + 1 == ps.size() ? (k + 1) << 8 : 0);
+          out.pieces.insert(out.pieces.end(), rec, rec + kPieceRec);
+          cost += piece_cost(ps[i].count);
+        }
+        for (int q = 0; q < kGroupJoints; ++q) out.row_joints.push_back(q < nq ? order[q] : -1);
+        ++row;
+        a = b;
+      }
+    } else {
+      for (size_t i = 0; i < ps.size(); ++i) {
+        const bool last = i + 1 == ps.size() || ps[i + 1].part != ps[i].part;
+        int32_t rec[kPieceRec] = {0};
+        rec[0] = ps[i].count;
+        for (int q = 0; q < 4; ++q) rec[1 + q] = ps[i].joints[q];
+        rec[9] = ps[i].start;
+        rec[10] = last ? row : -1;
+        out.pieces.insert(out.pieces.end(), rec, rec + kPieceRec);
+        cost += piece_cost(ps[i].count);
+        if (last) {
+          out.row_part.push_back(ps[i].part);
+          ++row;
+        }
+      }
+    }
+    out.max_cost = std::max(out.max_cost, cost);
+    out.piece_start.push_back((int32_t)(out.pieces.size() / kPieceRec));
+  }
+  out.nrows = row;
+  out.pieces.insert(out.pieces.end(), kPieceRec, 0);  // sentinel
+  for (int k = 0; k < ns; ++k)
+    if (out.piece_start[k + 1] == out.piece_start[k]) {  // (an empty cell: no table, see build_share_tables)
+      if (std::getenv("SMPLFIT_DUMP_SHARES")) std::fprintf(stderr, "kind %d: cell %d of %d is empty (total %ld)\n", kind, k, ns, total);
+      out.ncells = 0;
+    }
+}
+}  // namespace
+
+void build_share_tables(HostTables& t) {
+  t.shares.clear();
+  if (t.vpieces.empty()) return;
+  t.shares.resize(kShareKinds);
+  for (int k = 0; k < kShareKinds; ++k) {
+    build_share_table(t, k, t.shares[k]);
+    if (t.shares[k].ncells == 0) {  // a domain too small for its cells: the model stays on the wave-per-instance kernels
+      t.shares.clear();
+      return;
+    }
+  }
+}
+
+int pick_share_mult(const HostTables& t, int kind, int nblocks, int slots) {
+  // a wave's prologue (cell record, piece record, joints, first streams: dependent round trips) costs about a dozen steps
+  constexpr long kPrologue = 12;
+  const ShareTable& st = t.shares[kind];
+  int best = 1;
+  long best_cost = -1;
+  for (int m = 1; m <= 16 && st.ncells % (m * kBmWaves) == 0; m *= 2) {
+    const long waves = (long)nblocks * (st.ncells / m), rounds = (waves + slots - 1) / slots;
+    const long c = rounds * ((long)m * st.max_cost + kPrologue);
+    if (best_cost < 0 || c < best_cost) {
+      best_cost = c;
+      best = m;
+    }
+  }
+  return best;
+}
+
 std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsupported) {
   *unsupported = false;
   if (!d.v_template || !d.shapedirs || !d.posedirs || !d.weights || !d.J_template ||
@@ -310,96 +484,47 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
     };
     t.cpackA.assign((size_t)Vp * cs, 0.f);
     for (int i = 0; i < Vp; ++i) pack(t.cpackA.data() + (size_t)i * cs, i);
-    // vertex groups: greedy runs inside a part with at most kGroupJoints distinct joints
-    t.groups.clear();
+    // batch-major tables: the pieces of the sorted slots, the per-slot records, the share tables
     const int bs = t.brec_stride(), bw = t.brec_w();
     t.brec.assign((size_t)Vp * bs, 0.f);
-    t.pieces.clear();
-    t.piece_start.assign(1, 0);
-    // A maximal run is then cut into equal pieces of at most `cap` vertices: the groups are the
-    // workgroup units of the batch-major kernels, and SMPL's 22 runs of 224..483 vertices leave the chip
-    // with uneven rounds of workgroups.  Measured at B = 4096 with two chunks (M fits/s): no cut 1.43,
-    // cap 448 / 384: 1.48, 256: 1.46, 192: 1.46; below ~128 the staging + combine cost wins.
-    int cap = 384;
-    if (const char* e = std::getenv("SMPLFIT_GROUP_CAP")) cap = std::max(16, std::atoi(e));
-    for (int i = 0; i < V;) {
+    t.vpieces.clear();
+    for (int i = 0; i < V && t.KW == 4;) {  // (models with more than four weights per vertex never take these kernels)
       const int p = t.slot_part[i];
-      uint64_t set = 0;
+      uint64_t u = 0;
       int e = i;
       while (e < V && t.slot_part[e] == p) {
-        const uint64_t u = set | jmask[t.perm[e]];
-        if (__builtin_popcountll(u) > kGroupJoints) break;
-        set = u;
+        const uint64_t u2 = u | jmask[t.perm[e]];
+        if (__builtin_popcountll(u2) > 4) break;
+        u = u2;
         ++e;
       }
-      if (e == i) return "smplfit_create: a vertex has more skinning joints than a vertex group holds";
-      const int npc = (e - i + cap - 1) / cap;
-      for (int pc = 0; pc < npc; ++pc) {
-        const int a = i + (int)((int64_t)(e - i) * pc / npc), b = i + (int)((int64_t)(e - i) * (pc + 1) / npc);
-        VertexGroup g{};
-        g.start = a;
-        g.count = b - a;
-        g.part = p;
-        g.used = t.used_part[p] ? 1 : 0;
-        uint64_t pset = 0;
-        for (int s = a; s < b; ++s) pset |= jmask[t.perm[s]];
-        int local[kMaxJoints];
-        for (int j = 0; j < J; ++j)
-          if ((pset >> j) & 1) {
-            local[j] = g.nq;
-            g.joints[g.nq++] = j;
-          }
-        for (int q = g.nq; q < kGroupJoints; ++q) g.joints[q] = g.joints[0];
-        // the waves' shares (the kernels split [start, start + count) the same way) and their pieces
-        const int per = (g.count + kBmWaves - 1) / kBmWaves;
-        for (int w = 0; w < kBmWaves; ++w) {
-          const int wa = std::min(a + w * per, b), wb = std::min(wa + per, b);
-          size_t first = t.pieces.size();
-          // (models with more than four weights per vertex never take the batch-major kernels: no pieces)
-          for (int s = wa; s < wb && t.KW == 4;) {
-            uint64_t u = 0;
-            int e2 = s;
-            while (e2 < wb) {
-              const uint64_t u2 = u | jmask[t.perm[e2]];
-              if (__builtin_popcountll(u2) > 4) break;
-              u = u2;
-              ++e2;
-            }
-            if (e2 == s) return "smplfit_create: a vertex of the batch-major tables has more than 4 skinning joints";
-            int32_t rec[kPieceRec] = {0};
-            int nj = 0, pj[4] = {0, 0, 0, 0};
-            for (int j = 0; j < J; ++j)
-              if ((u >> j) & 1) pj[nj++] = j;
-            if (nj == 0) pj[nj++] = g.joints[0];  // (a vertex without weights: cannot happen for a valid model)
-            for (int k = nj; k < 4; ++k) pj[k] = pj[0];  // padding joints carry weight 0
-            rec[0] = e2 - s;  // vertices of the piece (the pieces of a wave are contiguous from its first slot)
-            for (int k = 0; k < 4; ++k) {
-              rec[1 + k] = pj[k];
-              rec[5 + k] = local[pj[k]];
-            }
-            t.pieces.insert(t.pieces.end(), rec, rec + kPieceRec);
-            for (int v = s; v < e2; ++v) {  // the vertex's weights in the piece's joint order
-              float* r = t.brec.data() + (size_t)v * bs;
-              for (int k = 0; k < nj; ++k) r[bw + k] = d.weights[(size_t)t.perm[v] * J + pj[k]];
-            }
-            s = e2;
-          }
-          (void)first;
-          t.piece_start.push_back((int32_t)(t.pieces.size() / kPieceRec));
-        }
-        for (int s = a; s < b; ++s) {
-          float* rec = t.brec.data() + (size_t)s * bs;
-          for (int s2 = 0; s2 < S; ++s2)
-            for (int c = 0; c < 3; ++c) rec[c * S + s2] = t.sd[(size_t)(c * S + s2) * Vp + s];
-        }
-        t.groups.push_back(g);
+      if (e == i) return "smplfit_create: a vertex of the batch-major tables has more than 4 skinning joints";
+      VertexPiece pc{};
+      pc.start = i;
+      pc.count = e - i;
+      pc.part = p;
+      pc.used = t.used_part[p] ? 1 : 0;
+      for (int j = 0; j < J; ++j)
+        if ((u >> j) & 1) pc.joints[pc.nj++] = j;
+      if (pc.nj == 0) pc.joints[pc.nj++] = p;  // (a vertex without weights: cannot happen for a valid model)
+      for (int k = pc.nj; k < 4; ++k) pc.joints[k] = pc.joints[0];  // padding joints carry weight 0
+      for (int v = i; v < e; ++v) {  // the vertex's weights in the piece's joint order
+        float* r = t.brec.data() + (size_t)v * bs;
+        for (int k = 0; k < pc.nj; ++k) r[bw + k] = d.weights[(size_t)t.perm[v] * J + pc.joints[k]];
       }
+      t.vpieces.push_back(pc);
       i = e;
     }
-    t.pieces.insert(t.pieces.end(), kPieceRec, 0);  // sentinel: a zero-length piece behind the last one
-    if (std::getenv("SMPLFIT_DUMP_GROUPS"))
-      for (const auto& g : t.groups)
-        std::fprintf(stderr, "group start %d count %d part %d used %d nq %d\n", g.start, g.count, g.part, g.used, g.nq);
+    for (int s = 0; s < V; ++s) {
+      float* rec = t.brec.data() + (size_t)s * bs;
+      for (int s2 = 0; s2 < S; ++s2)
+        for (int c = 0; c < 3; ++c) rec[c * S + s2] = t.sd[(size_t)(c * S + s2) * Vp + s];
+    }
+    build_share_tables(t);
+    if (std::getenv("SMPLFIT_DUMP_SHARES"))
+      for (size_t k = 0; k < t.shares.size(); ++k)
+        std::fprintf(stderr, "cells %d kind %zu: pieces %zu rows %d max_cost %d\n", t.shares[k].ncells, k,
+                     t.shares[k].pieces.size() / kPieceRec - 1, t.shares[k].nrows, t.shares[k].max_cost);
     t.cpackB.assign(t.segments.size() * 64 * cs, 0.f);
     for (size_t sgi = 0; sgi < t.segments.size(); ++sgi)
       for (int l = 0; l < t.segments[sgi].count; ++l)

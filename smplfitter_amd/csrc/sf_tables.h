@@ -34,22 +34,55 @@ struct Segment {
   int32_t start, count, part;
 };
 
-// Vertex group of the batch-major ("lane = instance") vertex kernels: a run of sorted slots of ONE part
-// whose skinning joints number at most kGroupJoints; the group's joint list is staged once per
-// workgroup and the per-vertex records address it by local slot.
-constexpr int kGroupJoints = 12;
-constexpr int kBmWaves = 4;   // waves of a batch-major vertex workgroup: they split the group's vertices evenly (measured in
-                              // round 3 with the piece kernels: 2 waves 1.89, 4 waves 1.95, 8 waves 1.90 M fits/s)
-// A wave's share of a group is cut into PIECES: maximal runs of slots whose skinning joints number at most four
-// together.  Inside a piece the vertex loops keep those four joints' records in registers (no LDS read per vertex)
-// and the per-joint sums in four accumulators; a vertex's record holds its weights in the piece's joint order.
-// Record: the piece's vertex count (a wave's pieces are contiguous from its first slot), joints[4] (model joint ids,
-// ascending, padded with the first), local[4] (their slots in the group's joint list), 3 unused.  The table ends
-// with one all-zero record, so that reading one record past a wave's last piece is always valid.
+// Batch-major ("lane = instance") vertex kernels: the sorted slots are cut once into PIECES — maximal runs of slots
+// of ONE part whose skinning joints number at most four together (within a part the slots are sorted by joint set, so
+// the runs are long).  Inside a piece the vertex loops keep those four joints' records in registers (no LDS read per
+// vertex) and the per-joint sums in four accumulators; a vertex's record (HostTables::brec) holds its weights in the
+// piece's joint order (ascending joint id).
+struct VertexPiece {
+  int32_t start, count, part, used, nj;
+  int32_t joints[4];  // ascending, padded with joints[0] (padding joints carry weight 0)
+};
+// The work of one instance block (64 instances) is cut into NC CELLS: runs of whole or split pieces of (nearly) equal
+// cost — cost = steps (a piece of odd length takes one padding step) + kPieceCost per piece (the exposed load of its
+// joints); NC = the largest power of two that leaves a cell ~75+ steps (SMPL 64, SMPL-X 128, a 1024-vertex subset 16).
+// A wave (a SHARE) walks `mult` consecutive cells; a launch picks the multiplier whose (rounds x share length) is
+// smallest for its number of instance blocks (pick_share_mult): at B = 4096 that is ONE round of 4096 equally long
+// waves where the part-aligned vertex groups of round 3 took 1.5 uneven rounds of workgroups.  No wave waits for
+// another one: every wave writes its own partial sums, restarting them at every cell boundary, so the ROWS of partial
+// sums (ws.psumP / ws.resP) and the order in which the combine kernels add them are the same whatever the multiplier:
+// an instance's result does not depend on the batch it is fitted in.
+constexpr int kGroupJoints = 12;  // local joint slots of a residual SEGMENT (moment accumulators of a wave in LDS)
+#ifndef SMPLFIT_BM_WAVES
+#define SMPLFIT_BM_WAVES 4
+#endif
+#ifndef SMPLFIT_CELL_STEPS
+#define SMPLFIT_CELL_STEPS 75  // a cell holds at least this many steps (and fewer than twice as many)
+#endif
+#ifndef SMPLFIT_PIECE_COST
+#define SMPLFIT_PIECE_COST 3
+#endif
+constexpr int kBmWaves = SMPLFIT_BM_WAVES;  // waves (= shares) per workgroup of the batch-major vertex kernels (1, 2 or 4)
+constexpr int kPieceCost = SMPLFIT_PIECE_COST;
+// Cell piece record (scalar loads): [0] vertex count, [1..4] joints, [5..8] their local slots in the current residual
+// segment, [9] first slot, [10] the output row block written AFTER this piece (-1: none), [11] residual tables: the
+// row's joint count | (cell index + 1) << 8 behind the LAST piece of a cell (there the wave also writes the cell's
+// r1 | Sb record).  Every table ends with one all-zero record: reading one record past the last piece is valid.
 constexpr int kPieceRec = 12;
-struct VertexGroup {
-  int32_t start, count, part, used, nq;
-  int32_t joints[kGroupJoints];  // padded with joints[0]
+enum ShareKind : int {
+  kShareResidual = 0,  // all slots; a row = a SEGMENT (run of pieces of one cell whose joints number <= kGroupJoints): moments
+  kShareLbsAll = 1,    // all slots; a row = the part sums of a run of one part inside a cell (joints-omitted fits, forward)
+  kShareLbsUsed = 2,   // the slots of the used parts (bodyfitter.py:109-114)
+  kShareLbsAdj = 3,    // the slots of the adjustable parts only: the LAST part sums of a fit feed the dependent
+                       // refinement alone, which reads them at the adjustable parts (bodyfitter.py:1505-1517)
+  kShareKinds = 4
+};
+struct ShareTable {
+  int ncells = 0, nrows = 0, max_cost = 0;
+  std::vector<int32_t> piece_start;  // (ncells + 1)
+  std::vector<int32_t> pieces;       // (npieces + 1, kPieceRec)
+  std::vector<int32_t> row_part;     // (nrows) LBS tables: the part of a row
+  std::vector<int32_t> row_joints;   // (nrows, kGroupJoints) residual tables: joint of every local slot, -1 = unused
 };
 
 struct HostTables {
@@ -134,10 +167,9 @@ struct HostTables {
   // slots; blob per tile = [64 x cstride() vertex records | 16 x 64 MFMA A-operand weights
   // (step t, lane l -> weight of vertex 4t + l/16 for joint slot l%16) | 16 joint ids (pad = J)]
   std::vector<Segment> gtiles;
-  // batch-major kernels: vertex groups and per-slot records = cpackA rows whose index words hold the
-  // LOCAL joint slots of the group (byte k = slot of the k-th skinning pair), and the dense weights over
-  // the group's joint list
-  std::vector<VertexGroup> groups;
+  // batch-major kernels: the pieces of the sorted slots and the cell tables cut from them, one per ShareKind
+  std::vector<VertexPiece> vpieces;
+  std::vector<ShareTable> shares;  // (kShareKinds), empty when the model has no batch-major tables
   // the batch-major pair-Gram kernel reads rows of shape values as aligned register PAIRS: its copies of the
   // constants have the y axis padded to an even length SE = S rounded up to 2 (the padding is zero)
   std::vector<float> pair_c1x;   // pair_c1 re-laid out as (np, S [x], 3 [a], 3 [a'], SE [y])
@@ -149,8 +181,6 @@ struct HostTables {
   std::vector<float> brec;       // (Vp, brec_stride())
   int brec_w() const { return (3 * S + 3) / 4 * 4; }  // offset of the weights
   int brec_stride() const { return brec_w() + 4; }
-  std::vector<int32_t> pieces;       // (npieces, kPieceRec)
-  std::vector<int32_t> piece_start;  // (ngroups * kBmWaves + 1) first piece of every (group, wave)
   std::vector<float> gblob;      // (ngt, gblob_stride())
   int gblob_stride() const { return 64 * cstride() + 16 * 64 + 16; }
 
@@ -172,5 +202,9 @@ struct HostTables {
 // Returns "" on success, else an error message (and `unsupported` tells which status to use).
 void build_tiled_gemm_images(HostTables& t);
 std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsupported);
+// Cells per share (1, 2, 4, ...) of a batch-major vertex pass of `kind` over `nblocks` instance blocks on `slots`
+// resident waves: the multiplier with the smallest rounds x (share length + prologue) estimate.
+int pick_share_mult(const HostTables& t, int kind, int nblocks, int slots);
+void build_share_tables(HostTables& t);
 
 }  // namespace sf

@@ -71,22 +71,22 @@ struct DevModel {
   const int32_t *reg_start, *reg_slot;
   const float* reg_val;
   const float* reg_rowsum;
-  // batch-major vertex kernels (HostTables::groups / brec / bwd)
-  int ngroups, ngroups_used;
-  const int32_t* groups;  // (ngroups, kGroupRec): start, count, part, used, nq, joints[12]
-  // launch order of the vertex groups, longest first (all groups / the used ones); lpt = 0 launches them in
-  // table order with the group index fastest
-  const int32_t *gorder_all, *gorder_used;
-  int lpt;
+  // batch-major vertex kernels (HostTables::vpieces / brec; the share tables travel as ShareView arguments)
+  int bm_tables;              // the model has batch-major tables (<= 4 skinning weights per vertex)
   const float* brec;          // (Vp, brec_stride) per-slot records: shapedirs + 4 weights in the piece's joint order
-  const int32_t* pieces;      // (npieces, kPieceRec) joint runs of every (group, wave), HostTables::pieces
-  const int32_t* piece_start; // (ngroups * kBW + 1)
   const float *pair_c1x, *pair_c2e, *diag_c2e;  // even-stride copies for k_pair_gram_bm (HostTables)
-  // per joint: the resP rows (group * kResRec + 16 + 3 * slot) holding its residual moments
-  const int32_t *mb_start, *mb_row;
 };
 
-constexpr int kGroupRec = 5 + sf::kGroupJoints;
+// One cell table on the device (sf::ShareTable) as the kernels take it, with the multiplier a launch picked.
+struct ShareView {
+  const int32_t* piece_start;  // (ncells + 1)
+  const int32_t* pieces;       // (npieces + 1, kPieceRec)
+  // LBS tables: rows of every part, CSR (part_row_start (J + 1), part_rows); residual tables: the resP rows holding a
+  // joint's residual moments, CSR (mb_start (J + 1), mb_row)
+  const int32_t *aux_start, *aux_rows;
+  int ncells, nrows;
+  int mult;  // cells per wave: share s walks the cells [s * mult, (s + 1) * mult)
+};
 
 }  // namespace
 
@@ -95,6 +95,8 @@ constexpr int kMaxChunks = 4;  // batch chunks of one fit call run on the caller
 struct smplfit_handle {
   sf::HostTables t;
   DevModel d{};
+  // the cell tables of the batch-major vertex kernels on the device: views[kind]
+  std::vector<ShareView> views;
   std::vector<void*> allocs;
   bool has_device = false;
   // registers per lane the split-bf16 GEMM kernels were built with (hipFuncGetAttributes at create).  They must own
@@ -194,12 +196,16 @@ struct Workspace {
   float* vpT;      // (Mp/64, 3*Vp, 64) v_posed, written by the GEMM
   float* tT;       // (Mp/64, 3*Vp, 64) targets AS GIVEN at their sorted slots (padding slots: the mean); the
                    // consumers subtract ws.mean (k_layout_targets / k_mean_finish)
-  float* psumP;    // (ngroups, 16, Mp) part sums per vertex group
-  float* resP;     // (ngroups, kResRec, Mp) residual-pass sums per vertex group
+  float* psumP;    // (rows, 16, Mp) part sums per row of the LBS share table
+  float* resP;     // ([share][16] + [segment row][3 kGQ], Mp) residual-pass sums (k_residual_bm); scratch of the layout pass
   float* gramP;    // (kGramChunks, NG, Mp) pair-Gram partial sums
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+#ifndef SMPLFIT_SLAB
+#define SMPLFIT_SLAB 32  // original vertices per workgroup of k_layout_targets (kSlabV)
+#endif
 
 // fwd_only: the slice a batch-major forward of this model needs (the input side of a fused conversion, see
 // smplfit_convert_f32): pose features, joint rows, shape / translation and the instance-innermost v_posed buffer.
@@ -246,8 +252,17 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w, bool fwd_
   ws.tjs = (float*)take((size_t)B * J * 3 * 4);
   ws.vpT = (float*)take(Mp * 3 * Vp * 4, true);
   ws.tT = (float*)take(Mp * 3 * Vp * 4);
-  ws.psumP = (float*)take((size_t)t.groups.size() * 16 * Mp * 4);
-  ws.resP = (float*)take((size_t)t.groups.size() * (16 + 3 * sf::kGroupJoints) * Mp * 4);
+  {
+    size_t lbs_rows = 0, res_rows = 0;
+    for (size_t k = 0; k < t.shares.size(); ++k) {
+      if (k == sf::kShareResidual) res_rows = (size_t)t.shares[k].ncells * 16 + (size_t)t.shares[k].nrows * 3 * sf::kGroupJoints;
+      else lbs_rows = std::max(lbs_rows, (size_t)t.shares[k].nrows);
+    }
+    // (the layout kernel's slab sums use ws.resP as scratch: 3 rows per slab)
+    const size_t nslab = ((size_t)t.V + SMPLFIT_SLAB - 1) / SMPLFIT_SLAB;
+    ws.psumP = (float*)take(lbs_rows * 16 * Mp * 4);
+    ws.resP = (float*)take(std::max(res_rows, 3 * nslab) * Mp * 4);
+  }
   ws.gramP = (float*)take((size_t)32 * (NE1 - 1) * Mp * 4);  // kGramChunks x NG (<= NE) x Mp
   ws.jdT = (float*)take(Mp * align_up((size_t)J * sf::jd_stride(S), 64) * 4, true);
   if (w) *w = ws;
@@ -274,7 +289,8 @@ struct Tuning {
   int chunks = 2;          // SMPLFIT_CHUNKS=1..4: concurrent batch chunks of one fit call
   int gemm_nchunk = 0;     // SMPLFIT_GEMM_NCHUNK: column-tile chunks of the split-bf16 GEMM (0 = automatic)
   int gemm_lds_kb = 0;     // SMPLFIT_GEMM_LDS_KB: LDS request of the fp32 A-stationary GEMM (occupancy experiments)
-  int lpt = 1;             // SMPLFIT_LPT=0: vertex groups launched in table order (read at smplfit_create)
+  bool lbs_all_last = false;  // SMPLFIT_LBS_LAST=all: the last part sums of a fit over every used part (A/B of the adjustable-parts pass)
+  int bm_slots = 4096;     // SMPLFIT_BM_SLOTS: resident waves a batch-major vertex pass is dealt for (share-count choice)
   int bm_lds_kb = 0;       // SMPLFIT_BM_LDS_KB: LDS request of the two batch-major vertex passes padded to this (54: three
                            // workgroups per CU instead of four, which leaves registers / LDS for another chunk's small kernels)
 };
@@ -290,7 +306,8 @@ void load_tuning() {
   if (const char* e = env("SMPLFIT_CHUNKS")) t.chunks = std::min(std::max(atoi(e), 1), 4);
   if (const char* e = env("SMPLFIT_GEMM_NCHUNK")) t.gemm_nchunk = std::max(1, atoi(e));
   if (const char* e = env("SMPLFIT_GEMM_LDS_KB")) t.gemm_lds_kb = atoi(e);
-  if (const char* e = env("SMPLFIT_LPT")) t.lpt = atoi(e);
+  if (const char* e = env("SMPLFIT_LBS_LAST")) t.lbs_all_last = e[0] == 'a';
+  if (const char* e = env("SMPLFIT_BM_SLOTS")) t.bm_slots = std::min(std::max(atoi(e), 256), 16384);
   if (const char* e = env("SMPLFIT_BM_LDS_KB")) t.bm_lds_kb = std::min(std::max(atoi(e), 0), 64);
   g_tune = t;
 }
@@ -313,10 +330,8 @@ bool use_bm() { return tune().bm; }
 bool bm_applies(const DevModel& d) {
   // (normalised skinning weights are checked where the handle is at hand: bm_applies(const smplfit_handle*))
   // Vp > V: the batch-major loops run their out-of-range steps on the first padding slot
-  // (below ~1000 vertices the staging of a workgroup's joints outweighs its vertex work)
-  // the layout kernel's slab sums use ws.resP as scratch: (slabs x 3) rows must fit its (groups x kResRec) rows
-  const bool slab_fit = 3 * ((d.V + kSlabV - 1) / kSlabV) <= d.ngroups * kResRec;
-  return use_bm() && d.KW == 4 && (d.S == 10 || d.S == 11) && d.ngroups > 0 && d.V >= 1024 && d.Vp > d.V && slab_fit;
+  // (below ~1000 vertices the prologue of a wave outweighs its vertex work)
+  return use_bm() && d.KW == 4 && (d.S == 10 || d.S == 11) && d.bm_tables && d.V >= 1024 && d.Vp > d.V;
 }
 
 // The batch-major residual kernel derives sum_v b_v from the per-joint moments: exact only when every vertex's
@@ -329,25 +344,44 @@ void launch_jd_transpose(const DevModel& d, const Workspace& ws, int B, hipStrea
   hipLaunchKernelGGL(k_transpose_targets, dim3(Np / 64, Mp / 64), dim3(256), 0, st, ws.jd, ws.jdT, B, Np, Mp, Ns);
 }
 
+// The cell table a batch-major vertex pass of `kind` over B instances runs on, with its multiplier (sf::pick_share_mult).
+ShareView share_view(const smplfit_handle* h, int kind, int B) {
+  const int nblocks = (int)align_up((size_t)B, 128) / 64;
+  ShareView sv = h->views[kind];
+  sv.mult = sf::pick_share_mult(h->t, kind, nblocks, tune().bm_slots);
+  return sv;
+}
+dim3 share_grid(const ShareView& sv, int Mp) { return dim3(Mp / 64, sv.ncells / sv.mult / kBW); }
+
+// part sums of the centred targets against the template + their combine (the first rotation estimate)
+void launch_template_partsum_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStream_t st) {
+  const DevModel& d = h->d;
+  const int Mp = (int)align_up((size_t)B, 128);
+  const ShareView sv = share_view(h, sf::kShareLbsUsed, B);
+  hipLaunchKernelGGL(k_template_partsum_bm, share_grid(sv, Mp), dim3(64 * kBW), 0, st, d, sv, ws, B, Mp);
+  hipLaunchKernelGGL(k_psum_combine, dim3((B + 255) / 256, d.J), dim3(256), 0, st, d, sv, ws, B, Mp);
+}
+
 // One-pass target layout of the batch-major path (k_layout_targets, k_mean_finish, k_template_partsum_bm):
 // ws.tT, ws.mean, ws.tjc and the template part sums ws.psum.  ws.resP serves as the slab-sum scratch.
-void launch_layout_bm(const DevModel& d, const float* tv, const float* tj, const Workspace& ws, int B, hipStream_t st) {
+void launch_layout_bm(const smplfit_handle* h, const float* tv, const float* tj, const Workspace& ws, int B, hipStream_t st) {
+  const DevModel& d = h->d;
   const int Mp = (int)align_up((size_t)B, 128), nslab = (d.V + kSlabV - 1) / kSlabV;
   hipLaunchKernelGGL(k_layout_targets, dim3(nslab, Mp / 64), dim3(256), (size_t)64 * kSlabRow * 4, st, d, tv, ws.tT,
                      ws.resP, B, Mp);
   hipLaunchKernelGGL(k_mean_finish, dim3(Mp / 64), dim3(64 * kMeanWaves), 0, st, d, tj, ws.resP, ws, B, Mp, nslab);
-  hipLaunchKernelGGL(k_template_partsum_bm, d.lpt ? dim3(Mp / 64, d.ngroups_used) : dim3(d.ngroups_used, Mp / 64),
-                     dim3(64 * kBW), 0, st, d, ws, B, Mp);
-  hipLaunchKernelGGL(k_psum_combine, dim3((B + 255) / 256, d.J), dim3(256), 0, st, d, ws, B, Mp);
+  launch_template_partsum_bm(h, ws, B, st);
 }
 
 // K3' + K3g + K3c of the batch-major path for 10 betas (S = 10) and 10 betas + the kid unknown (S = 11)
 template <int S>
-void launch_residual_bm_s(const DevModel& d, const Workspace& ws, int B, hipStream_t st, int which = 7) {
+void launch_residual_bm_s(const smplfit_handle* h, const Workspace& ws, int B, hipStream_t st, int which = 7) {
+  const DevModel& d = h->d;
   const int Mp = (int)align_up((size_t)B, 128);
+  const ShareView sv = share_view(h, sf::kShareResidual, B);
   if (which & 1)
-    hipLaunchKernelGGL((k_residual_bm<S>), d.lpt ? dim3(Mp / 64, d.ngroups) : dim3(d.ngroups, Mp / 64),
-                       dim3(64 * kBW), std::max(kResidualLds, (size_t)tune().bm_lds_kb * 1024), st, d, ws, B, Mp);
+    hipLaunchKernelGGL((k_residual_bm<S>), share_grid(sv, Mp), dim3(64 * kBW),
+                       std::max(kResidualLds, (size_t)tune().bm_lds_kb * 1024), st, d, sv, ws, B, Mp);
   if (which & 2) {
     if constexpr (S > 10) {  // two launches over the rows of the Gramian (see k_pair_gram_bm)
       hipLaunchKernelGGL((k_pair_gram_bm<S, 1>), dim3(kGramChunks, Mp / 64), dim3(64), 0, st, d, ws, B, Mp);
@@ -358,30 +392,33 @@ void launch_residual_bm_s(const DevModel& d, const Workspace& ws, int B, hipStre
   }
   if (which & 4)
     hipLaunchKernelGGL((k_gram_combine_bm<S>), dim3((B + 255) / 256, S + 3 + 3 * d.J + sf::ne_ng(S)), dim3(256), 0,
-                       st, d, ws, B, Mp);
+                       st, d, sv, ws, B, Mp);
 }
-void launch_residual_bm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, int which = 7) {
-  if (d.S == 11) launch_residual_bm_s<11>(d, ws, B, st, which);
-  else launch_residual_bm_s<10>(d, ws, B, st, which);
+void launch_residual_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStream_t st, int which = 7) {
+  if (h->d.S == 11) launch_residual_bm_s<11>(h, ws, B, st, which);
+  else launch_residual_bm_s<10>(h, ws, B, st, which);
 }
 
-// write_v (joints-omitted fits): all groups, the vertices at the solution written over ws.vpT, then the reference
-// joints of the next rotation pass regressed from them into ws.rjreg
+// write_v (joints-omitted fits): every slot, the vertices at the solution written over ws.vpT, then the reference
+// joints of the next rotation pass regressed from them into ws.rjreg.  adj_only (the last pass of a fit with target
+// joints): the part sums feed the dependent refinement alone, which reads them at the adjustable parts
+// (bodyfitter.py:1505-1517) — only those parts' slots are visited, the other rows of ws.psum become zero.
 template <int S, int KW>
-void launch_lbs_bm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, bool write_v = false) {
+void launch_lbs_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStream_t st, bool write_v = false,
+                   bool adj_only = false) {
+  const DevModel& d = h->d;
   const int Mp = (int)align_up((size_t)B, 128);
-  const size_t lds = std::max(kLbsLds, (size_t)tune().bm_lds_kb * 1024);
+  const size_t lds = (size_t)tune().bm_lds_kb * 1024;
+  const ShareView sv = share_view(h, write_v ? sf::kShareLbsAll : adj_only ? sf::kShareLbsAdj : sf::kShareLbsUsed, B);
   if constexpr (KW == 4 && S <= 12) {  // what bm_applies admits (10 betas with or without the kid unknown)
     if (write_v) {
-      hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4, true>), d.lpt ? dim3(Mp / 64, d.ngroups) : dim3(d.ngroups, Mp / 64),
-                         dim3(64 * kBW), lds, st, d, ws, B, Mp);
+      hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4, true>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp);
       hipLaunchKernelGGL(k_regress_joints_bm<false>, dim3(Mp / 64, d.J), dim3(64), 0, st, d, ws.vpT, nullptr, ws.rjreg, B);
     } else {
-      hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4>), d.lpt ? dim3(Mp / 64, d.ngroups_used) : dim3(d.ngroups_used, Mp / 64),
-                         dim3(64 * kBW), lds, st, d, ws, B, Mp);
+      hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp);
     }
   }
-  hipLaunchKernelGGL(k_psum_combine, dim3((B + 255) / 256, d.J), dim3(256), 0, st, d, ws, B, Mp);
+  hipLaunchKernelGGL(k_psum_combine, dim3((B + 255) / 256, d.J), dim3(256), 0, st, d, sv, ws, B, Mp);
 }
 
 template <int S, int KW>
@@ -693,7 +730,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   if (bm && o.source) {
     if (int rc = launch_convert_source(*o.source, d, ws, B, st)) return rc;
   } else if (bm) {
-    launch_layout_bm(d, tv, tj, ws, B, st);
+    launch_layout_bm(h, tv, tj, ws, B, st);
   }
   const float* tj_rot = ws.tjc;
   if (!joints) {  // regressed target joints from the centred vertices (bodyfitter.py:1342-1344)
@@ -761,8 +798,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
       // joint rows instance-innermost for the three kernels below; AFTER the GEMM: in front of it the
       // chunk's GEMM starts later and the chunks overlap worse (1.37 vs 1.40 M fits/s)
       launch_jd_transpose(d, ws, B, st);
-      const size_t lds = kResidualLds;
-      launch_residual_bm(d, ws, B, st);
+      launch_residual_bm(h, ws, B, st);
     } else {
       launch_gemm(d, ws, B, st);
 #define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, B, eff_v, st)
@@ -778,7 +814,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     const bool last = it + 1 == o.num_iter;
     if (last && !o.final_adjust) break;  // nothing consumes the re-evaluated mesh
     if (bm) {
-#define SF_CALL_LBS(S_, KW_) launch_lbs_bm<S_, KW_>(d, ws, B, st, !joints)
+#define SF_CALL_LBS(S_, KW_) launch_lbs_bm<S_, KW_>(h, ws, B, st, !joints, last && joints && !tune().lbs_all_last)
       SF_DISPATCH_SKW(d, SF_CALL_LBS);
 #undef SF_CALL_LBS
     } else if (joints) {
@@ -922,20 +958,18 @@ int launch_convert_source(const ConvertSource& src, const DevModel& d, const Wor
   if (int rc = launch_gemm(di, wi, B, st, true)) return rc;
   launch_jd_transpose(di, wi, B, st);
   {
-    const size_t lds = kLbsLds;
-    const dim3 grid = di.lpt ? dim3(Mp / 64, di.ngroups) : dim3(di.ngroups, Mp / 64);
+    const ShareView sv = share_view(pl.in, sf::kShareLbsAll, B);
+    const dim3 grid = share_grid(sv, Mp);
     if (di.S == 11)
-      hipLaunchKernelGGL((k_lbs_partsum_bm<11, 4, true, true>), grid, dim3(64 * kBW), lds, st, di, wi, B, Mp);
+      hipLaunchKernelGGL((k_lbs_partsum_bm<11, 4, true, true>), grid, dim3(64 * kBW), 0, st, di, sv, wi, B, Mp);
     else
-      hipLaunchKernelGGL((k_lbs_partsum_bm<10, 4, true, true>), grid, dim3(64 * kBW), lds, st, di, wi, B, Mp);
+      hipLaunchKernelGGL((k_lbs_partsum_bm<10, 4, true, true>), grid, dim3(64 * kBW), 0, st, di, sv, wi, B, Mp);
   }
   TransferTabs tt{pl.d_oslot, pl.d_start, pl.d_islot, pl.d_w, d.V};
   hipLaunchKernelGGL(k_transfer_bm, dim3(pl.nslab, Mp / 64), dim3(256), 0, st, tt, wi.vpT, di.Vp, ws.tT, d.Vp, ws.resP, Mp);
   hipLaunchKernelGGL(k_mean_finish, dim3(Mp / 64), dim3(64 * kMeanWaves), 0, st, d, (const float*)nullptr, ws.resP, ws, B, Mp,
                      pl.nslab);
-  hipLaunchKernelGGL(k_template_partsum_bm, d.lpt ? dim3(Mp / 64, d.ngroups_used) : dim3(d.ngroups_used, Mp / 64),
-                     dim3(64 * kBW), 0, st, d, ws, B, Mp);
-  hipLaunchKernelGGL(k_psum_combine, dim3((B + 255) / 256, d.J), dim3(256), 0, st, d, ws, B, Mp);
+  launch_template_partsum_bm(pl.out, ws, B, st);
   return 0;
 }
 
@@ -1107,7 +1141,8 @@ const char* smplfit_last_error(void) { return g_last_error.c_str(); }
 #ifndef SMPLFIT_BUILD_ID
 #define SMPLFIT_BUILD_ID "unknown"
 #endif
-const char* smplfit_version(void) { return "smplfit-hip 0.2 (gfx950) build " SMPLFIT_BUILD_ID; }
+const char* smplfit_version(void) { return "smplfit-hip 0.4 (gfx950) build " SMPLFIT_BUILD_ID; }
+int smplfit_abi_version(void) { return SMPLFIT_ABI_VERSION; }
 
 int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** out) {
   if (!desc || !out) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_create: null argument");
@@ -1206,44 +1241,43 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
   up(t.reg_val, &d.reg_val);
   up(t.reg_rowsum, &d.reg_rowsum);
   {
-    std::vector<int32_t> gr;
-    d.ngroups = (int)t.groups.size();
-    d.ngroups_used = 0;
-    for (const auto& g : t.groups) {
-      gr.push_back(g.start); gr.push_back(g.count); gr.push_back(g.part); gr.push_back(g.used);
-      gr.push_back(g.nq);
-      for (int q = 0; q < sf::kGroupJoints; ++q) gr.push_back(g.joints[q]);
-      if (g.used) ++d.ngroups_used;  // used parts come first in slot order
-    }
-    up(gr, &d.groups);
     {
       std::vector<int32_t> inv(t.V, 0);
       for (int i = 0; i < t.Vp; ++i)
         if (t.perm[i] >= 0) inv[t.perm[i]] = i;
       up(inv, &d.inv_slot);
     }
-    {
-      std::vector<int32_t> oa(t.groups.size()), ou;
-      for (size_t g = 0; g < oa.size(); ++g) oa[g] = (int32_t)g;
-      std::stable_sort(oa.begin(), oa.end(), [&](int32_t a, int32_t b) { return t.groups[a].count > t.groups[b].count; });
-      for (int32_t g : oa)
-        if (g < d.ngroups_used) ou.push_back(g);
-      up(oa, &d.gorder_all);
-      up(ou, &d.gorder_used);
-      d.lpt = tune().lpt;
+    // the share tables of the batch-major vertex kernels
+    d.bm_tables = t.shares.empty() ? 0 : 1;
+    h->views.assign(t.shares.size(), ShareView{});
+    for (size_t i = 0; i < t.shares.size(); ++i) {
+      const sf::ShareTable& stb = t.shares[i];
+      ShareView& sv = h->views[i];
+      sv.ncells = stb.ncells;
+      sv.nrows = stb.nrows;
+      sv.mult = 1;
+      up(stb.piece_start, &sv.piece_start);
+      up(stb.pieces, &sv.pieces);
+      std::vector<int32_t> astart(t.J + 1, 0), arows;
+      if ((int)(i % sf::kShareKinds) == sf::kShareResidual) {  // per joint: the resP rows holding its moments
+        for (int j = 0; j < t.J; ++j) {
+          for (int r = 0; r < stb.nrows; ++r)
+            for (int q = 0; q < sf::kGroupJoints; ++q)
+              if (stb.row_joints[(size_t)r * sf::kGroupJoints + q] == j)
+                arows.push_back((int32_t)(stb.ncells * kResShareRec + r * kResRowRec + 3 * q));
+          astart[j + 1] = (int32_t)arows.size();
+        }
+      } else {  // per part: its rows of ws.psumP
+        for (int j = 0; j < t.J; ++j) {
+          for (int r = 0; r < stb.nrows; ++r)
+            if (stb.row_part[r] == j) arows.push_back(r);
+          astart[j + 1] = (int32_t)arows.size();
+        }
+      }
+      up(astart, &sv.aux_start);
+      up(arows, &sv.aux_rows);
     }
-    std::vector<int32_t> mb_start(t.J + 1, 0), mb_row;
-    for (int j = 0; j < t.J; ++j) {
-      for (size_t g = 0; g < t.groups.size(); ++g)
-        for (int q = 0; q < t.groups[g].nq; ++q)
-          if (t.groups[g].joints[q] == j) mb_row.push_back((int32_t)(g * (16 + 3 * sf::kGroupJoints) + 16 + 3 * q));
-      mb_start[j + 1] = (int32_t)mb_row.size();
-    }
-    up(mb_start, &d.mb_start);
-    up(mb_row, &d.mb_row);
     up(t.brec, &d.brec);
-    up(t.pieces, &d.pieces);
-    up(t.piece_start, &d.piece_start);
     up(t.pair_c1x, &d.pair_c1x);
     up(t.pair_c2e, &d.pair_c2e);
     up(t.diag_c2e, &d.diag_c2e);
@@ -1351,14 +1385,18 @@ int smplfit_get_table(const smplfit_handle* h, int table_id, int32_t* dst, size_
       }
       src = &tmp;
       break;
-    case SMPLFIT_TAB_VERTEX_GROUPS:
-      for (auto& g : t.groups) {
+    case SMPLFIT_TAB_VERTEX_PIECES:
+      for (auto& g : t.vpieces) {
         tmp.push_back(g.start);
         tmp.push_back(g.count);
         tmp.push_back(g.part);
         tmp.push_back(g.used);
-        tmp.push_back(g.nq);
+        tmp.push_back(g.nj);
       }
+      src = &tmp;
+      break;
+    case SMPLFIT_TAB_CELL_COUNTS:
+      for (auto& st : t.shares) tmp.push_back(st.ncells);
       src = &tmp;
       break;
     default: return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_get_table: unknown table id");
@@ -1366,6 +1404,24 @@ int smplfit_get_table(const smplfit_handle* h, int table_id, int32_t* dst, size_
   *n = src->size();
   if (dst) std::memcpy(dst, src->data(), std::min(cap, src->size()) * sizeof(int32_t));
   return SMPLFIT_OK;
+}
+
+int smplfit_get_share_table(const smplfit_handle* h, int kind, int what, int32_t* dst, size_t cap, size_t* n) {
+  if (!h || !n) return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_get_share_table: null argument");
+  const sf::HostTables& t = h->t;
+  if (kind < 0 || kind >= (int)t.shares.size() || what < 0 || what > 2)
+    return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_get_share_table: unknown kind / table (or a model without batch-major tables)");
+  const sf::ShareTable& st = t.shares[kind];
+  const std::vector<int32_t>* src =
+      what == 0 ? &st.piece_start : what == 1 ? &st.pieces : (kind == sf::kShareResidual ? &st.row_joints : &st.row_part);
+  *n = src->size();
+  if (dst) std::memcpy(dst, src->data(), std::min(cap, src->size()) * sizeof(int32_t));
+  return SMPLFIT_OK;
+}
+
+int smplfit_pick_share_mult(const smplfit_handle* h, int kind, int batch) {
+  if (!h || kind < 0 || kind >= (int)h->t.shares.size() || batch <= 0) return -1;
+  return sf::pick_share_mult(h->t, kind, (int)align_up((size_t)batch, 128) / 64, tune().bm_slots);
 }
 
 size_t smplfit_workspace_bytes(const smplfit_handle* h, int batch) {
@@ -1793,7 +1849,7 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
       case SMPLFIT_KERNEL_POSEDIRS_GEMM: return launch_gemm(d, ws, batch, st, bm);
       case SMPLFIT_KERNEL_PAIR_GRAM:
         if (!bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "pair-Gram kernel: batch-major path not active");
-        launch_residual_bm(d, ws, batch, st, 2);
+        launch_residual_bm(h, ws, batch, st, 2);
         return 0;
       case SMPLFIT_KERNEL_TRANSPOSE:
         if (!bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "layout kernel: batch-major path not active");
@@ -1803,12 +1859,14 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
         return 0;
       case SMPLFIT_KERNEL_TEMPLATE_PARTSUM:
         if (!bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "template part sums: batch-major path not active");
-        hipLaunchKernelGGL(k_template_partsum_bm, d.lpt ? dim3(Mp / 64, d.ngroups_used) : dim3(d.ngroups_used, Mp / 64),
-                           dim3(64 * kBW), 0, st, d, ws, batch, Mp);
+        {
+          const ShareView sv = share_view(h, sf::kShareLbsUsed, batch);
+          hipLaunchKernelGGL(k_template_partsum_bm, share_grid(sv, Mp), dim3(64 * kBW), 0, st, d, sv, ws, batch, Mp);
+        }
         return 0;
       case SMPLFIT_KERNEL_SHAPE_ACCUM: {
         if (bm) {
-          launch_residual_bm(d, ws, batch, st, 1);
+          launch_residual_bm(h, ws, batch, st, 1);
           return 0;
         }
 #define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, batch, false, st)
@@ -1822,8 +1880,8 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
         return 0;
       case SMPLFIT_KERNEL_LBS_PARTSUM: {
         if (bm) {
-          if (d.S == 11) launch_lbs_bm<11, 4>(d, ws, batch, st);
-          else launch_lbs_bm<10, 4>(d, ws, batch, st);
+          if (d.S == 11) launch_lbs_bm<11, 4>(h, ws, batch, st);
+          else launch_lbs_bm<10, 4>(h, ws, batch, st);
           return 0;
         }
 #define SF_CALL_LBS(S_, KW_) \
@@ -1870,6 +1928,14 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
   *avg_ms = ms / (float)reps;
   return post_launch_check();
 }
+
+#ifdef SMPLFIT_WAVE_STAMPS
+// debug builds: the stamps of the last k_residual_bm launch (n waves x 5 values), see kernels_bm.inc
+int smplfit_debug_wave_stamps(unsigned long long* dst, int n) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wave_stamps), (size_t)n * 5 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int smplfit_primitives_f32(int primitive_id, const float* a, const float* b, float* out, int n,
                            void* hip_stream) {

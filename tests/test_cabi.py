@@ -79,22 +79,81 @@ def test_host_tables_match_reference_structure(lib, name, model_root, golden):
     for s, c, p in seg:  # every segment is one part, at most one wave wide
         assert 0 < c <= 64 and (of.part[perm[s:s + c]] == p).all()
     assert h.info.skin_width == 4 and h.info.padded_vertices % 128 == 0
-    # vertex groups (workgroup units of the batch-major kernels): a partition of the sorted slots into
-    # runs of one part, at most 384 vertices and 12 skinning joints each, used parts first; and at least
-    # one padding slot behind the vertices whenever those kernels can apply
-    grp = h.table('vertex_groups').reshape(-1, 5)
-    assert grp[0, 0] == 0 and (grp[1:, 0] == grp[:-1, 0] + grp[:-1, 1]).all()
-    assert grp[-1, 0] + grp[-1, 1] == V
-    assert (grp[:, 1] > 0).all() and (grp[:, 1] <= 384).all() and (grp[:, 4] >= 1).all() and (grp[:, 4] <= 12).all()
-    for s, c, p, u, nq in grp:
+    # pieces (what the batch-major vertex kernels walk): a partition of the sorted slots into runs of one part
+    # with at most four skinning joints each, used parts first; and at least one padding slot behind the
+    # vertices whenever those kernels can apply
+    pcs = h.table('vertex_pieces').reshape(-1, 5)
+    assert pcs[0, 0] == 0 and (pcs[1:, 0] == pcs[:-1, 0] + pcs[:-1, 1]).all()
+    assert pcs[-1, 0] + pcs[-1, 1] == V
+    assert (pcs[:, 1] > 0).all() and (pcs[:, 4] >= 1).all() and (pcs[:, 4] <= 4).all()
+    for s, c, p, u, nq in pcs:
         assert (of.part[perm[s:s + c]] == p).all() and u == int(p in of.used_parts)
         joints = np.unique(np.nonzero(md.weights[perm[s:s + c]])[1])
         assert len(joints) == nq
-    assert (np.diff(grp[:, 3]) <= 0).all()  # used groups first
+    assert (np.diff(pcs[:, 3]) <= 0).all()  # used pieces first
+    check_share_tables(h, of, md, perm, V)
     if V >= 1024:
         assert h.info.padded_vertices > V
     assert h.workspace_bytes(64) > 0
     h.close()
+
+
+def check_share_tables(h, of, md, perm, V):
+    """Every cell table deals its domain (all slots / used parts / adjustable parts) exactly once to its cells, in
+    cells of nearly equal cost, and its rows say where the partial sums go."""
+    ncells = h.table('cell_counts')
+    assert len(ncells) == 4 and all(n >= 8 and n & (n - 1) == 0 for n in ncells)  # powers of two
+    slot_part = of.part[perm[:V]]
+    domains = {0: np.ones(V, bool), 1: np.ones(V, bool), 2: np.isin(slot_part, of.used_parts),
+               3: np.isin(slot_part, sorted(of.adjustable))}
+    for kind in range(4):
+        nc = int(ncells[kind])
+        start = h.share_table(kind, 0)
+        rec = h.share_table(kind, 1).reshape(-1, 12)
+        rows = h.share_table(kind, 2)
+        assert len(start) == nc + 1 and start[0] == 0 and start[-1] == len(rec) - 1
+        assert (rec[-1] == 0).all()  # sentinel
+        seen = np.zeros(V, np.int32)
+        costs, row = [], 0
+        for k in range(nc):
+            cost, slots = 0, {}
+            assert start[k + 1] > start[k]  # no empty cell
+            for r in rec[start[k]:start[k + 1]]:
+                cnt, js, loc, s0, close, tail = r[0], r[1:5], r[5:9], r[9], r[10], r[11]
+                assert cnt > 0
+                seen[s0:s0 + cnt] += 1
+                cost += cnt + (cnt & 1) + 3
+                assert len(set(slot_part[s0:s0 + cnt])) == 1
+                used_j = set(np.unique(np.nonzero(md.weights[perm[s0:s0 + cnt]])[1]))
+                assert used_j <= set(js.tolist())
+                if kind == 0:
+                    for j, q in zip(js, loc):  # local slots are stable inside a segment
+                        assert 0 <= q < 12 and slots.setdefault(int(j), int(q)) == q
+                if close >= 0:
+                    assert close == row
+                    if kind == 0:
+                        rj = rows.reshape(-1, 12)[row]
+                        assert (tail & 0xff) == len(slots) == (rj >= 0).sum()
+                        assert all(rj[q] == j for j, q in slots.items())
+                        slots = {}
+                    else:
+                        assert rows[row] == slot_part[s0]
+                    row += 1
+            last = rec[start[k + 1] - 1]
+            assert last[10] >= 0  # a cell always closes its last row: the rows do not depend on the multiplier
+            if kind == 0:
+                assert (last[11] >> 8) == k + 1 and all((r[11] >> 8) == 0 for r in rec[start[k]:start[k + 1] - 1])
+            costs.append(cost)
+        assert (seen == domains[kind].astype(np.int32)).all()
+        assert row == (len(rows) // 12 if kind == 0 else len(rows))
+        # balanced: the longest cell is within a few steps of the mean (the last one may be shorter)
+        assert max(costs) <= np.mean(costs) + 8, (kind, max(costs), np.mean(costs))
+        assert np.mean(costs) >= 60  # cells of ~75+ steps
+    # multiplier: one round of the chip where the batch allows it
+    lib = _lib.load()
+    if V > 6000:
+        m4k, m32k = lib.smplfit_pick_share_mult(h.ptr, 0, 4096), lib.smplfit_pick_share_mult(h.ptr, 0, 32768)
+        assert (4096 // 64) * ncells[0] // m4k == 4096 and (32768 // 64) * ncells[0] // m32k == 4096
 
 
 def test_create_rejects_bad_models(lib, model_root):
