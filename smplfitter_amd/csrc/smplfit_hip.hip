@@ -269,6 +269,30 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w, bool fwd_
   return off;
 }
 
+// Cache policy of the streams.  The per-iteration streams of a fit (v_posed, the targets: 0.34 GB each at B = 4096)
+// are written once and read once per pass, and together they are several times the 256 MB Infinity Cache and the
+// 32 MB of L2: left to the default policy, the producer's output lingers as dirty lines that the NEXT kernel's reads
+// push out — its write-back then competes with those reads (measured, B = 4096: the residual pass takes 178 us behind
+// the GEMM, 145 us on its own) — and the streams evict the tables every wave re-reads.  Marked non-temporal, stream
+// reads and writes pass through: residual 178 -> 126 us, LBS 142 -> 120, GEMM 106 -> 97, layout 150 -> 126,
+// 2.01 -> 2.4 M fits/s, bit-identical results.  SMPLFIT_NT selects which accesses carry the hint (A/B builds):
+// 1 stream loads of the batch-major vertex passes, 2 GEMM output stores, 4 target loads of the layout pass (slower:
+// 139 us — off), 8 its stores (and the topology transfer's), 16 the streams of the wave-per-instance kernels (K0's
+// sorted copy, the reads of K3 / K5).
+#ifndef SMPLFIT_NT
+#define SMPLFIT_NT 27
+#endif
+template <int BIT>
+__device__ __forceinline__ float ld_stream(const float* p) {
+  if constexpr ((SMPLFIT_NT & BIT) != 0) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <int BIT>
+__device__ __forceinline__ void st_stream(float* p, float v) {
+  if constexpr ((SMPLFIT_NT & BIT) != 0) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
 // the kernels (same anonymous namespace, same translation unit)
 #include "kernels_wave.inc"
 #include "kernels_bm.inc"
@@ -1896,7 +1920,9 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
   // Each timed launch runs right after the kernel that precedes it inside a fit (K2 before K3, K3
   // before K5), so caches are in the state the kernel sees in situ; only the target kernel is
   // bracketed by the two events.
+  const bool nopre = getenv("SMPLFIT_TIME_NOPRE") != nullptr;  // (measurement hook only: the kernel without its producer in front)
   auto pre = [&]() {
+    if (nopre) return 0;
     if (kernel_id == SMPLFIT_KERNEL_SHAPE_ACCUM) launch_gemm(d, ws, batch, st, bm);
     if (kernel_id == SMPLFIT_KERNEL_LBS_PARTSUM && bm)
       hipLaunchKernelGGL(k_shape_solve, dim3(batch), dim3(64), solve_lds(d), st, d, ws, 1.0f, 0.0f, 1.0f, 1, 0);
