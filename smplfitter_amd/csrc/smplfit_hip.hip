@@ -310,7 +310,7 @@ struct Tuning {
   bool gemm_f32 = false;   // SMPLFIT_GEMM=f32: fp32-MFMA posedirs GEMM instead of the split-bf16 one
   bool pair_form = false;  // SMPLFIT_SHAPE_FORM=pair: pair-Gram form on the wave-per-instance path
   bool k0_two = true;      // SMPLFIT_K0_TWO=0: K0 stages the whole row (one workgroup per CU)
-  int chunks = 2;          // SMPLFIT_CHUNKS=1..4: concurrent batch chunks of one fit call
+  int chunks = 0;          // SMPLFIT_CHUNKS=1..4: concurrent batch chunks of one fit call (0: by model, see chunk_plan)
   int gemm_nchunk = 0;     // SMPLFIT_GEMM_NCHUNK: column-tile chunks of the split-bf16 GEMM (0 = automatic)
   int gemm_lds_kb = 0;     // SMPLFIT_GEMM_LDS_KB: LDS request of the fp32 A-stationary GEMM (occupancy experiments)
   bool lbs_all_last = false;  // SMPLFIT_LBS_LAST=all: the last part sums of a fit over every used part (A/B of the adjustable-parts pass)
@@ -735,7 +735,14 @@ int enqueue_solve(const DevModel& d, const Workspace& ws, int B, const FitOption
 
 int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const float* vw,
             const float* jw, int B, const FitOptions& o, float* pose, float* betas, float* trans,
-            float* kid, float* orient, float* rel, const Workspace& ws, hipStream_t st) {
+            float* kid, float* orient, float* rel, const Workspace& ws, hipStream_t st, int ph_lo = 0,
+            int ph_hi = 1 << 30) {
+  // PHASES.  The launches of a fit are numbered in phases — 0: the prologue up to the first rotation pass; 1 + 2 it:
+  // the vertex block of iteration `it` up to the normal equations; 2 + 2 it: solve, vertices at the solution, next
+  // rotation pass; 1 + 2 num_iter: refinement and epilogue — and a call enqueues the phases [ph_lo, ph_hi) only (the
+  // host-side state is rebuilt every time): a chunked fit enqueues its chunks phase by phase, alternating between
+  // their streams, instead of one whole chunk after the other (fit_impl).
+  const auto on = [&](int ph) { return ph >= ph_lo && ph < ph_hi; };
   const DevModel& d = h->d;
   const bool joints = tj != nullptr;
   if (!joints && !h->t.has_regressor)
@@ -750,15 +757,17 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   if (o.source && !bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "fused conversion: the batch-major path does not apply");
   // a warm-started fit evaluates its first part sums against the posed model with the wave-per-instance
   // kernel, which reads the per-instance sorted copy ws.tvs: that copy is produced as well then
-  if (!bm || o.init_pose || o.init_betas) launch_center_sort(d, tv, tj, vw, ws, B, st);
-  if (bm && o.source) {
+  if (on(0) && (!bm || o.init_pose || o.init_betas)) launch_center_sort(d, tv, tj, vw, ws, B, st);
+  if (!on(0)) {
+  } else if (bm && o.source) {
     if (int rc = launch_convert_source(*o.source, d, ws, B, st)) return rc;
   } else if (bm) {
     launch_layout_bm(h, tv, tj, ws, B, st);
   }
   const float* tj_rot = ws.tjc;
   if (!joints) {  // regressed target joints from the centred vertices (bodyfitter.py:1342-1344)
-    if (bm)
+    if (!on(0)) {
+    } else if (bm)
       hipLaunchKernelGGL(k_regress_joints_bm<true>, dim3((int)align_up((size_t)B, 128) / 64, d.J), dim3(64), 0, st, d,
                          ws.tT, ws.mean, ws.tjreg, B);
     else
@@ -779,7 +788,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   // initial_kid_factor on its own (:413-414, :448-449)
   const bool warm = o.init_pose || o.init_betas;
   const int use_ref = (o.init_betas || o.init_kid) ? 1 : 0;
-  if (warm || use_ref)
+  if (on(0) && (warm || use_ref))
     hipLaunchKernelGGL(k_fill_shape, dim3((B + 255) / 256), dim3(256), 0, st, ws, B, d.S, d.jt.n_kid,
                        o.init_betas, std::min(o.init_nb, d.S - d.jt.n_kid - d.jt.n_pad), o.init_kid);
   if (warm) {
@@ -789,14 +798,16 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     fa.nb = d.S;
     fa.joints = ws.rjoints;
     fa.orient = ws.G;
-    hipLaunchKernelGGL(k_forward_joint, dim3(B), dim3(64), joint_lds(d), st, d, fa, ws);
-    launch_gemm(d, ws, B, st);
+    if (on(0)) {
+      hipLaunchKernelGGL(k_forward_joint, dim3(B), dim3(64), joint_lds(d), st, d, fa, ws);
+      launch_gemm(d, ws, B, st);
 #define SF_CALL_LBS(S_, KW_) \
   launch_lbs<S_, KW_, 1, false>(d, ws, B, vweighted, d.S, ws.beta, ws.trans, nullptr, 0.f, 0.f, st)
-    SF_DISPATCH_SKW(d, SF_CALL_LBS);
+      SF_DISPATCH_SKW(d, SF_CALL_LBS);
 #undef SF_CALL_LBS
-    if (!joints)
-      hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(64), 0, st, d, ws.rverts, ws.rjreg);
+      if (!joints)
+        hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(64), 0, st, d, ws.rverts, ws.rjreg);
+    }
     ja.rj = joints ? ws.rjoints : ws.rjreg;
     ja.rj_shared = 0;
     ja.Gprev = ws.G;  // compose with the initial orientations
@@ -804,17 +815,19 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     ja.rj = d.j_template;
     ja.rj_shared = 1;
   } else {  // template joints regressed from the default mesh: same regressor on a (1,3,Vp) source
-    hipLaunchKernelGGL(k_regress_joints, dim3(1), dim3(64), 0, st, d, d.dm, ws.rjreg);
+    if (on(0)) hipLaunchKernelGGL(k_regress_joints, dim3(1), dim3(64), 0, st, d, d.dm, ws.rjreg);
     ja.rj = ws.rjreg;
     ja.rj_shared = 1;
   }
-  hipLaunchKernelGGL(k_joint_stage, dim3(B), dim3(64), joint_lds(d), st, d, ja, ws);
+  if (on(0)) hipLaunchKernelGGL(k_joint_stage, dim3(B), dim3(64), joint_lds(d), st, d, ja, ws);
   if (o.rotations_only) {
-    hipLaunchKernelGGL(k_copy, dim3(256), dim3(256), 0, st, ws.G, orient, (size_t)B * d.J * 9);
+    if (on(0)) hipLaunchKernelGGL(k_copy, dim3(256), dim3(256), 0, st, ws.G, orient, (size_t)B * d.J * 9);
     return post_launch_check();
   }
   for (int it = 0; it < o.num_iter; ++it) {
-    if (bm) {
+    const bool pa = on(1 + 2 * it), pb = on(2 + 2 * it);
+    if (!pa) {
+    } else if (bm) {
       // batch-major vertex block: one transposed GEMM feeds the residual pass and, after the solve,
       // the LBS / part-sum pass of this iteration
       const int Mp = (int)align_up((size_t)B, 128);
@@ -833,11 +846,12 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     // ~40 serial barriers stall all four waves of the workgroup and the kernel ran 230 us longer
     const int pair_in = (bm || (!eff_v && use_pair_form())) ? 1 : 0;
     const bool scaled_now = o.scale_mode && it + 1 == o.num_iter;  // only the last solve (:434-455)
-    if (int rc = enqueue_solve(d, ws, B, o, joints, eff_v, eff_j, jw, pair_in, use_ref, scaled_now, st))
-      return rc;
+    if (pb)
+      if (int rc = enqueue_solve(d, ws, B, o, joints, eff_v, eff_j, jw, pair_in, use_ref, scaled_now, st)) return rc;
     const bool last = it + 1 == o.num_iter;
     if (last && !o.final_adjust) break;  // nothing consumes the re-evaluated mesh
-    if (bm) {
+    if (!pb) {
+    } else if (bm) {
 #define SF_CALL_LBS(S_, KW_) launch_lbs_bm<S_, KW_>(h, ws, B, st, !joints, last && joints && !tune().lbs_all_last)
       SF_DISPATCH_SKW(d, SF_CALL_LBS);
 #undef SF_CALL_LBS
@@ -857,8 +871,9 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     ja.rj = joints ? ws.rjoints : ws.rjreg;
     ja.rj_shared = 0;
     ja.Gprev = ws.G;
-    hipLaunchKernelGGL(k_joint_stage, dim3(B), dim3(64), joint_lds(d), st, d, ja, ws);
+    if (pb) hipLaunchKernelGGL(k_joint_stage, dim3(B), dim3(64), joint_lds(d), st, d, ja, ws);
   }
+  if (!on(1 + 2 * o.num_iter)) return post_launch_check();
   RefineArgs ra{};
   ra.tj = tj_rot;
   ra.rj_term = joints ? ws.rjoints : ws.rjreg;
@@ -1008,12 +1023,18 @@ int upload(smplfit_handle* h, const std::vector<T>& src, const T** dst) {
   return 0;
 }
 
-// Chunk plan of one fit call: large batches are split into chunks (default 2, SMPLFIT_CHUNKS=1..4) that run concurrently on
+// Chunk plan of one fit call: a large batch may be split into chunks (SMPLFIT_CHUNKS=1..4) that run concurrently on
 // the caller's stream and the handle's side streams, so that the small latency-bound kernels of one chunk run beside
-// the heavy kernels of the other (measured +4 % at B = 4096; the GEMM itself never shares a CU).
+// the heavy kernels of the other (the GEMM itself never shares a CU).  Default, measured at B = 4096 in round 4 (the
+// streams non-temporal, the vertex passes one balanced round): the SMPL-shaped model 2.40 M fits/s in one chunk,
+// 2.37 in two, 2.21 in three; the SMPL-X-shaped one 1.13 M in one, 1.20 in two — its per-instance stages (55 joints)
+// are a larger share of the fit: two chunks for models with more than 32 joints, one otherwise.
 // Chunk sizes are multiples of 128 (the GEMM's instance tile).
-int chunk_plan(int batch, int* sizes) {
-  int n = std::min(tune().chunks, kMaxChunks);  // default 2; measured at B = 4096: 1 chunk 1.73, 2: 1.79, 3: 1.75, 4: 1.74 M fits/s
+int chunk_count(const sf::HostTables& t) {
+  const int c = tune().chunks;
+  return std::min(c > 0 ? c : (t.J > 32 ? 2 : 1), kMaxChunks);
+}
+int chunk_plan_n(int n, int batch, int* sizes) {
   while (n > 1 && batch < n * 512) --n;  // keep every chunk >= 512 instances
   const int per = ((batch + n - 1) / n + 127) / 128 * 128;
   int left = batch, k = 0;
@@ -1024,15 +1045,21 @@ int chunk_plan(int batch, int* sizes) {
   }
   return k;
 }
+int chunk_plan(const sf::HostTables& t, int batch, int* sizes) { return chunk_plan_n(chunk_count(t), batch, sizes); }
 
-// `tin`: the input model of a fused conversion — every chunk's slice is followed by that model's forward-only slice
+// `tin`: the input model of a fused conversion — every chunk's slice is followed by that model's forward-only slice.
+// Sized for every chunk count a call may pick (the tuning options can be reloaded between the two calls).
 size_t chunked_workspace_bytes(const sf::HostTables& t, int batch, const sf::HostTables* tin) {
-  int sizes[kMaxChunks];
-  const int n = chunk_plan(batch, sizes);
-  size_t total = 0;
-  for (int i = 0; i < n; ++i)
-    total += carve(t, sizes[i], nullptr, nullptr) + (tin ? carve(*tin, sizes[i], nullptr, nullptr, true) : 0);
-  return std::max(total, carve(t, batch, nullptr, nullptr) + (tin ? carve(*tin, batch, nullptr, nullptr, true) : 0));
+  size_t need = 0;
+  for (int n = 1; n <= kMaxChunks; ++n) {
+    int sizes[kMaxChunks];
+    const int k = chunk_plan_n(n, batch, sizes);
+    size_t total = 0;
+    for (int i = 0; i < k; ++i)
+      total += carve(t, sizes[i], nullptr, nullptr) + (tin ? carve(*tin, sizes[i], nullptr, nullptr, true) : 0);
+    need = std::max(need, total);
+  }
+  return need;
 }
 
 // the input side of a fused conversion, whole batch (fit_impl cuts it into the chunks' ConvertSource)
@@ -1085,13 +1112,13 @@ int fit_impl(const smplfit_handle* h, const smplfit_fit_args* args, const Conver
   hipStream_t st = (hipStream_t)hip_stream;
   int sizes[kMaxChunks];
   // share_beta couples all instances in every shape solve: one chunk
-  const int nchunk = (h->have_streams && !o.share_beta) ? chunk_plan(batch, sizes) : 1;
+  const int nchunk = (h->have_streams && !o.share_beta) ? chunk_plan(h->t, batch, sizes) : 1;
   const int J = h->t.J, V = h->t.V, Sb = h->t.num_betas();
   const int Jin = job ? job->plan->in->t.J : 0;
   auto chunk_bytes = [&](int nb) {
     return carve(h->t, nb, nullptr, nullptr) + (job ? carve(job->plan->in->t, nb, nullptr, nullptr, true) : 0);
   };
-  auto run_chunk = [&](int b0, int nb, char* wsbase, hipStream_t cs) -> int {
+  auto run_chunk = [&](int b0, int nb, char* wsbase, hipStream_t cs, int ph_lo, int ph_hi) -> int {
     Workspace ws;
     const size_t own = carve(h->t, nb, wsbase, &ws);
     FitOptions oc = o;
@@ -1117,38 +1144,62 @@ int fit_impl(const smplfit_handle* h, const smplfit_fit_args* args, const Conver
                    pose_rotvecs + (size_t)b0 * J * 3, shape_betas + (size_t)b0 * Sb,
                    trans + (size_t)b0 * 3, kid_factor ? kid_factor + b0 : nullptr,
                    orientations ? orientations + (size_t)b0 * J * 9 : nullptr,
-                   relative_orientations ? relative_orientations + (size_t)b0 * J * 9 : nullptr, ws, cs);
+                   relative_orientations ? relative_orientations + (size_t)b0 * J * 9 : nullptr, ws, cs, ph_lo, ph_hi);
   };
-  if (nchunk <= 1) return run_chunk(0, batch, (char*)workspace, st);
+  if (nchunk <= 1) return run_chunk(0, batch, (char*)workspace, st, 0, 1 << 30);
   // fork: every chunk is an independent fit with its own workspace slice; chunk 0 stays on the
   // caller's stream, the others go to the handle's side streams and are joined back by events
   // (stream-ordered with respect to the caller, hipGraph-capturable).  The handle's streams and
   // events are shared state: concurrent fit calls on one handle serialise their ENQUEUE here.
+  // The chunks are enqueued PHASE BY PHASE (run_fit), alternating between their streams: enqueued one whole chunk
+  // after the other, the second chunk's first kernel waits for the host to get through the ~30 launches of the
+  // first.  (Measured and not kept, round 4: a deliberate offset between the chunks — chunk c starting when chunk
+  // c - 1 has finished k phases, so that the bandwidth-bound kernels of one meet the latency-bound ones of the other:
+  // 2.37 M fits/s without, 2.23 / 2.19 / 2.10 with k = 1 / 2 / 3: the offset is paid again at the join of every call.)
   std::lock_guard<std::mutex> lock(h->mu);
   SF_HIP_TRY(hipEventRecord(h->ev_fork, st));
-  char* wsp = (char*)workspace;
-  int b0 = 0, first_error = 0;
+  const int nphase = 2 + 2 * num_iter;
+  int b0s[kMaxChunks], first_error = 0;
+  char* wsps[kMaxChunks];
+  {
+    char* wsp = (char*)workspace;
+    int b0 = 0;
+    for (int c = 0; c < nchunk; ++c) {
+      b0s[c] = b0;
+      wsps[c] = wsp;
+      wsp += chunk_bytes(sizes[c]);
+      b0 += sizes[c];
+    }
+  }
   std::string first_msg;
-  for (int c = 0; c < nchunk; ++c) {
-    hipStream_t cs = c == 0 ? st : h->side[c - 1];
-    // a failed fork is an error like any other: the chunks forked before it are still joined below
-    hipError_t fe = c > 0 ? hipStreamWaitEvent(cs, h->ev_fork, 0) : hipSuccess;
-    rc = fe != hipSuccess ? fail(SMPLFIT_ERR_HIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(fe))
-                          : run_chunk(b0, sizes[c], wsp, cs);
-    if (rc && !first_error) {
-      first_error = rc;
+  bool forked[kMaxChunks] = {true, false, false, false};
+  auto note = [&](int rc2) {
+    if (rc2 && !first_error) {
+      first_error = rc2;
       first_msg = g_last_error;
     }
-    // a chunk that was forked is always joined back, also after an error: an unjoined fork would
-    // invalidate a stream capture and leave work in flight that the caller's stream does not wait for
-    if (c > 0 && fe == hipSuccess) {
-      (void)hipEventRecord(h->ev_join[c - 1], cs);
+  };
+  for (int ph = 0; ph < nphase && !first_error; ++ph)
+    for (int c = 0; c < nchunk && !first_error; ++c) {
+      hipStream_t cs = c == 0 ? st : h->side[c - 1];
+      if (ph == 0 && c > 0) {
+        // a failed fork is an error like any other: the chunks forked before it are still joined below
+        const hipError_t fe = hipStreamWaitEvent(cs, h->ev_fork, 0);
+        if (fe != hipSuccess) {
+          note(fail(SMPLFIT_ERR_HIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(fe)));
+          break;
+        }
+        forked[c] = true;
+      }
+      note(run_chunk(b0s[c], sizes[c], wsps[c], cs, ph, ph + 1));
+    }
+  // a chunk that was forked is always joined back, also after an error: an unjoined fork would
+  // invalidate a stream capture and leave work in flight that the caller's stream does not wait for
+  for (int c = 1; c < nchunk; ++c)
+    if (forked[c]) {
+      (void)hipEventRecord(h->ev_join[c - 1], h->side[c - 1]);
       (void)hipStreamWaitEvent(st, h->ev_join[c - 1], 0);
     }
-    if (first_error) break;
-    wsp += chunk_bytes(sizes[c]);
-    b0 += sizes[c];
-  }
   if (first_error) return fail(first_error, first_msg);
   return SMPLFIT_OK;
 }

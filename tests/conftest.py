@@ -71,3 +71,10 @@ def smplfit_env(monkeypatch):
     yield set_var
     monkeypatch.undo()
     _lib.reload_options()
+
+
+@pytest.fixture
+def two_chunks(smplfit_env):
+    """Run a test's fits as two concurrent chunks (fork / join over the handle's side stream) whatever the model's
+    default is — one chunk for the SMPL-shaped model since round 4."""
+    smplfit_env('SMPLFIT_CHUNKS', '2')

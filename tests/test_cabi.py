@@ -243,12 +243,25 @@ def test_transfer_create_validates(lib):
     assert lib.smplfit_convert_f32(None, None) == _lib.SMPLFIT_ERR_BAD_ARG
 
 
-def test_reload_options(lib, monkeypatch):
-    """The tuning variables are read once; smplfit_reload_options() picks up a change (workspace size follows the
-    chunk count only through the chunk plan, so the call itself is the observable here)."""
+def test_reload_options(lib, monkeypatch, model_root, golden):
+    """The tuning variables are read once; smplfit_reload_options() picks up a change: the cells a wave of the vertex
+    passes walks at B = 4096 follow SMPLFIT_BM_SLOTS (one round of 4096 waves by default, two cells per wave when the
+    pass is dealt for 2048 resident waves)."""
+    import hostemu_util as H
+
     from smplfitter_amd import _lib
 
-    monkeypatch.setenv('SMPLFIT_CHUNKS', '1')
+    kind, md = util.load_md(model_root, 'smpl', golden('smpl'))
+    desc, keep = H.desc_from_md(md, kind)
+    h = _lib.Handle(desc, host_only=True)
+    monkeypatch.delenv('SMPLFIT_BM_SLOTS', raising=False)
     _lib.reload_options()
-    monkeypatch.delenv('SMPLFIT_CHUNKS')
+    assert lib.smplfit_pick_share_mult(h.ptr, 0, 4096) == 1
+    monkeypatch.setenv('SMPLFIT_BM_SLOTS', '2048')
+    assert lib.smplfit_pick_share_mult(h.ptr, 0, 4096) == 1  # not re-read yet
     _lib.reload_options()
+    assert lib.smplfit_pick_share_mult(h.ptr, 0, 4096) == 2
+    monkeypatch.delenv('SMPLFIT_BM_SLOTS')
+    _lib.reload_options()
+    assert lib.smplfit_pick_share_mult(h.ptr, 0, 4096) == 1
+    h.close()

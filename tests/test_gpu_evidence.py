@@ -375,6 +375,7 @@ def test_workspace_guards(name, model_root, golden, dev):
             assert torch.equal(out['zero'][k], out['nan'][k]), k
 
 
+@pytest.mark.usefixtures('two_chunks')
 @pytest.mark.parametrize('name,B,reps', [('smpl', 4096, 200), ('smplx', 2048, 60)])
 def test_neighbour_stress(name, B, reps, model_root, golden, dev):
     """The split-bf16 GEMMs must never share a CU with another kernel (k_posedirs_gemm_bf16x3 and, for the SMPL-X-shaped

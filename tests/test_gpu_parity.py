@@ -398,6 +398,7 @@ def test_convert_cross_topology(tag, path, model_root, golden, dev, data_root_fa
         pose, betas, trans, known_output_pose_rotvecs=t(gc[f'{tag}.kpose.pose_in'], dev))), gc)
 
 
+@pytest.mark.usefixtures('two_chunks')
 def test_convert_fused_matches_unfused(model_root, golden, dev, data_root_fat, monkeypatch, smplfit_env):
     """The fused conversion against the three separate calls on a batch that is chunked (B = 1100 -> two chunks, the
     second partial) and on the same-topology pair: same algorithm, different kernels and summation orders."""
@@ -684,6 +685,7 @@ def test_share_beta_sharded(world, backend, model_root, tmp_path):
         assert d == 0 if world == 1 else d < tol, (n, d)
 
 
+@pytest.mark.usefixtures('two_chunks')
 @pytest.mark.parametrize('B', [48, 2304])
 def test_hipgraph_capture(B, model_root, golden, dev):
     """A fit enqueues kernels only (no allocation, no host read, no device sync; the chunked form forks
@@ -746,6 +748,7 @@ def test_scale_goldens(name, model_root, golden, dev):
     assert err < 1e-2 and abs(r['scale_corr'].mean().item() - 1.1) < 0.05
 
 
+@pytest.mark.usefixtures('two_chunks')
 def test_concurrent_calls_on_one_handle(model_root, golden, dev):
     """Two host threads fitting through the SAME model handle at once (each on its own stream, own
     workspace): the chunked fit's shared side streams / events are guarded, results equal serial ones."""
