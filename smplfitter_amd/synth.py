@@ -132,6 +132,15 @@ def make_model_arrays(kind='smpl', seed=0, num_vertices=None, num_betas=10, shuf
     on the fat variant a tight pose_rotvecs comparison is meaningful."""
     if kind.endswith('_b16'):  # the same construction with 16 shape directions ('smpl_b16')
         kind, num_betas = kind[:-4], 16
+    # skinning variants: '_w6' keeps the SIX largest weights of a vertex (real models are not capped at four: the
+    # reference blends with the dense (V, J) matrix, pt/bodyfitter.py:1000-1003); '_rnd' gives every vertex its own
+    # part (weight 0.75) and THREE RANDOM other joints — joint sets the distance-based construction never produces
+    # (the vertex-piece / cell tables of the batch-major kernels must cope with any of them)
+    skin_nnz, skin_random = 4, False
+    if kind.endswith('_w6'):
+        kind, skin_nnz = kind[:-3], 6
+    if kind.endswith('_rnd'):
+        kind, skin_random = kind[:-4], True
     fat = kind.endswith('_fat')
     kind = kind[:-4] if fat else kind
     rs = np.random.RandomState(seed)
@@ -193,11 +202,18 @@ def make_model_arrays(kind='smpl', seed=0, num_vertices=None, num_betas=10, shuf
     logits = -dist / sigma
     logits -= logits.max(axis=1, keepdims=True)
     w = np.exp(logits)
-    top4 = np.argsort(-w, axis=1, kind='stable')[:, :4]
+    top = np.argsort(-w, axis=1, kind='stable')[:, :skin_nnz]
     keep = np.zeros_like(w, dtype=bool)
-    keep[np.arange(V)[:, None], top4] = True
+    keep[np.arange(V)[:, None], top] = True
     w = np.where(keep, w, 0.0)
     w /= w.sum(axis=1, keepdims=True)
+    if skin_random:
+        rs2 = np.random.RandomState(seed + 77)
+        w = np.zeros_like(w)
+        w[np.arange(V), gen_part] = 0.75
+        for v in range(V):
+            others = rs2.choice([j for j in range(J) if j != gen_part[v]], size=3, replace=False)
+            w[v, others] = 0.25 * rs2.dirichlet(np.ones(3))
     weights = w.astype(np.float64)
 
     # joint regressor: row-normalised gaussian over the 60 nearest vertices of each joint

@@ -80,18 +80,20 @@ def vertex_path(request, smplfit_env):
     return request.param
 
 
-@pytest.mark.parametrize('name', ['smpl', 'smplx', 'smpl1024'])
+@pytest.mark.parametrize('name', ['smpl', 'smplx', 'smpl1024', *util.SKIN_KINDS])
 def test_fit_goldens(name, model_root, golden, dev, vertex_path):
     g = golden(name)
     kind, md = util.load_md(model_root, name, g)
     om64, _ = util.make_oracle(md, kind, np.float64)
     m, f = get_model(model_root, name, g, dev)
+    if name in util.SKIN_KINDS:  # six weights per vertex: eight (joint, weight) pairs, wave-per-instance kernels only
+        assert m._native(dev).info.skin_width == (8 if name.endswith('_w6') else 4)
     # pose: 3e-4 on the well-conditioned SMPL fixtures (the host emulation of this arithmetic sits at
     # <= 2.2e-4 on all 32 option combinations; the reference's own fp32 floor is 3e-4); the
     # thin-finger SMPL-X fixture is ill-conditioned in the reference itself (pt vs fp64: 5e-4) and is judged
     # on vertices (its fat-part twin is gated in test_gpu_evidence.py::test_parity_statistics)
-    pose_tol = 5e-3 if name == 'smplx' else 3e-4
-    beta_tol = 3e-4 if name == 'smplx' else 1e-4
+    pose_tol = 5e-3 if name in ('smplx', 'smplx_w6') else 3e-4
+    beta_tol = 3e-4 if name in ('smplx', 'smplx_w6') else 1e-4
     for c in util.fit_configs(g):
         cfg = util.cfg_from_name(c)
         if not cfg['joints'] and name == 'smpl1024':
@@ -111,6 +113,18 @@ def test_fit_goldens(name, model_root, golden, dev, vertex_path):
         assert np.abs(o['pose_rotvecs'] - ref['pose_rotvecs']).max() < pose_tol, c
         assert np.abs(o['orientations'] - ref['orientations']).max() < pose_tol, c
         assert set(o) == {'pose_rotvecs', 'shape_betas', 'trans', 'orientations', 'relative_orientations'}
+    if name in util.SKIN_KINDS:  # the kid unknown and the forward on the same models
+        from smplfitter_amd.pt import BodyFitter
+
+        fw = to_np(m(t(g['pose'], dev), t(g['betas'], dev), t(g['trans'], dev)))
+        assert np.abs(fw['vertices'] - g['target_vertices']).max() < 2e-6
+        assert np.abs(fw['joints'] - g['fwd_joints']).max() < 2e-6
+        o = to_np(BodyFitter(m, enable_kid=True).fit(t(g['kid.target_vertices'], dev), t(g['kid.target_joints'], dev), num_iter=3,
+                                                     beta_regularizer=1.0, requested_keys=['pose_rotvecs', 'shape_betas', 'trans']))
+        ref = {k: g[f'kidfit.a.{k}'] for k in ('pose_rotvecs', 'shape_betas', 'trans', 'kid_factor')}
+        va = om64.forward(o['pose_rotvecs'], o['shape_betas'], o['trans'], kid_factor=o['kid_factor'])['vertices']
+        vb = om64.forward(ref['pose_rotvecs'], ref['shape_betas'], ref['trans'], kid_factor=ref['kid_factor'])['vertices']
+        assert np.linalg.norm(va - vb, axis=-1).max() < 1e-4
 
 
 @pytest.mark.parametrize('name', ['smpl', 'smplx'])
@@ -188,7 +202,7 @@ def test_edge_batches(model_root, golden, dev):
         m(pose_rotvecs=np.zeros((1, 72), np.float32))
 
 
-@pytest.mark.parametrize('name,B', [('smpl', 4096), ('smplx', 4096), ('smpl1024', 16384)])
+@pytest.mark.parametrize('name,B', [('smpl', 4096), ('smplx', 4096), ('smpl1024', 16384), ('smpl_w6', 4096), ('smpl_rnd', 4096)])
 def test_full_size_properties(name, B, model_root, golden, dev, vertex_path):
     """BASELINE.json configs 2-4 at full size: round trip (the reference's own acceptance test,
     tests/test_fitter_common.py:31-72: mean vertex / joint error < 5e-3 m after fit -> forward),

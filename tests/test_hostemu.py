@@ -51,14 +51,14 @@ def test_forward(name, model_root, golden):
     assert np.abs(fw2['vertices'] - g['target_vertices']).max() < 5e-6
 
 
-@pytest.mark.parametrize('name', ['smpl', 'smplx', 'smpl1024', 'smplxfat'])
+@pytest.mark.parametrize('name', ['smpl', 'smplx', 'smpl1024', 'smplxfat', *util.SKIN_KINDS])
 def test_fit_goldens(name, model_root, golden):
     g = golden(name)
     kind, md = util.load_md(model_root, name, g)
     om64, of64 = util.make_oracle(md, kind, np.float64)
     # 3e-4 on the well-conditioned fixtures (SMPL, fat-part SMPL-X); the thin-finger SMPL-X one is
     # ill-conditioned in the reference itself and is judged on vertices
-    pose_tol = 5e-3 if name == 'smplx' else (3e-4 if name in ('smpl', 'smplxfat') else 1.5e-3)
+    pose_tol = util.pose_tol(name)
     G0 = None
     for c in util.fit_configs(g):
         cfg = util.cfg_from_name(c)

@@ -49,18 +49,21 @@ def test_stage_goldens(name, model_root, golden):
     assert np.abs(r['vertices'][:, ::300] - g['stage.vertices0_sub']).max() < 2e-5
 
 
-@pytest.mark.parametrize('name', ['smpl', 'smplx', 'smpl1024', 'smplxfat'])
+@pytest.mark.parametrize('name', ['smpl', 'smplx', 'smpl1024', 'smplxfat', *util.SKIN_KINDS])
 @pytest.mark.parametrize('dtype', [np.float32, np.float64])
 def test_fit_goldens(name, dtype, model_root, golden):
     g = golden(name)
     kind, md = util.load_md(model_root, name, g)
     if name == 'smplxfat':  # the box regenerated the same fat-part model the reference was run on
         assert synth.model_sha256(synth.make_model_arrays('smplx_fat', 0)) == str(g['model_sha256'])
+    if name in util.SKIN_KINDS:  # the skinning variants (tests/golden/make_golden_skin.py)
+        assert synth.model_sha256(synth.make_model_arrays(name, 0)) == str(g['model_sha256'])
+        assert (md.weights != 0).sum(1).max() == int(g['skin_nnz']) == (6 if name.endswith('_w6') else 4)
     om, of = util.make_oracle(md, kind, dtype)
     om64, _ = util.make_oracle(md, kind, np.float64)
     # pose_rotvecs: the thin-finger SMPL-X fixture is ill-conditioned in the reference itself; on the
     # fat-part twin (tests/golden/make_golden_fat.py) and on SMPL the restatement sits within 3e-4
-    pose_tol = 5e-3 if name == 'smplx' else (3e-4 if name in ('smpl', 'smplxfat') else 1.5e-3)
+    pose_tol = util.pose_tol(name)
     for c in util.fit_configs(g):
         cfg = util.cfg_from_name(c)
         o = of.fit(
