@@ -648,12 +648,31 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
     }
     tof(c1, t.pair_c1); tof(c2, t.pair_c2); tof(c3, t.pair_c3);
     const int SE = t.s_even();
-    t.pair_c1x.assign((size_t)np * S * 9 * SE, 0.f);
+    // symmetrised pair constants of the batch-major pair-Gram kernel: entry e = (i <= i2) of the upper triangle in
+    // row-major order, E[p][aa'][e] = c1[aa'][i][i2] + c1[aa'][i2][i] (the Gramian collects f[i][i2] + f[i2][i])
+    const int NGP = t.ng_pad();
+    t.pair_E.assign((size_t)np * 9 * NGP, 0.f);
     for (int p = 0; p < np; ++p)
-      for (int aa = 0; aa < 9; ++aa)
-        for (int x = 0; x < S; ++x)
-          for (int y = 0; y < S; ++y)
-            t.pair_c1x[(((size_t)p * S + x) * 9 + aa) * SE + y] = t.pair_c1[(((size_t)p * 9 + aa) * S + x) * S + y];
+      for (int aa = 0; aa < 9; ++aa) {
+        int e = 0;
+        for (int i = 0; i < S; ++i)
+          for (int i2 = i; i2 < S; ++i2, ++e)
+            t.pair_E[((size_t)p * 9 + aa) * NGP + e] = t.pair_c1[(((size_t)p * 9 + aa) * S + i) * S + i2] +
+                                                      t.pair_c1[(((size_t)p * 9 + aa) * S + i2) * S + i];
+      }
+    // neighbours of every joint: (other joint, pair) for each pair the joint is part of
+    t.jn_start.assign(J + 1, 0);
+    t.jn.clear();
+    for (int j = 0; j < J; ++j) {
+      for (int p = 0; p < np; ++p) {
+        const int j1 = t.pair_j[2 * p], j2 = t.pair_j[2 * p + 1];
+        if (j1 == j || j2 == j) {
+          t.jn.push_back(j1 == j ? j2 : j1);
+          t.jn.push_back(p);
+        }
+      }
+      t.jn_start[j + 1] = (int32_t)(t.jn.size() / 2);
+    }
     t.pair_c2e.assign((size_t)np * 3 * SE, 0.f);
     for (int p = 0; p < np; ++p)
       for (int a = 0; a < 3; ++a)

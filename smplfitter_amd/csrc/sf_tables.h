@@ -172,7 +172,9 @@ struct HostTables {
   std::vector<ShareTable> shares;  // (kShareKinds), empty when the model has no batch-major tables
   // the batch-major pair-Gram kernel reads rows of shape values as aligned register PAIRS: its copies of the
   // constants have the y axis padded to an even length SE = S rounded up to 2 (the padding is zero)
-  std::vector<float> pair_c1x;   // pair_c1 re-laid out as (np, S [x], 3 [a], 3 [a'], SE [y])
+  std::vector<float> pair_E;     // (np, 9 [a a'], ng_pad()) symmetrised pair_c1 over the upper triangle (i <= i2, row-major)
+  std::vector<int32_t> jn_start, jn;  // per joint: its (other joint, pair) neighbours, CSR (J + 1) / (n, 2)
+  int ng_pad() const { return (S * (S + 1) / 2 + 3) / 4 * 4; }
   std::vector<float> pair_c2e;   // pair_c2 as (np, 3, SE)
   std::vector<float> diag_c2e;   // diag_c2 as (J, 3, SE)
   int s_even() const { return (S + 1) & ~1; }

@@ -74,7 +74,8 @@ struct DevModel {
   // batch-major vertex kernels (HostTables::vpieces / brec; the share tables travel as ShareView arguments)
   int bm_tables;              // the model has batch-major tables (<= 4 skinning weights per vertex)
   const float* brec;          // (Vp, brec_stride) per-slot records: shapedirs + 4 weights in the piece's joint order
-  const float *pair_c1x, *pair_c2e, *diag_c2e;  // even-stride copies for k_pair_gram_bm (HostTables)
+  const float *pair_E, *pair_c2e, *diag_c2e;  // constants of k_pair_gram_bm (HostTables)
+  const int32_t *jn_start, *jn;               // neighbours of every joint (HostTables::jn)
 };
 
 // One cell table on the device (sf::ShareTable) as the kernels take it, with the multiplier a launch picked.
@@ -198,7 +199,7 @@ struct Workspace {
                    // consumers subtract ws.mean (k_layout_targets / k_mean_finish)
   float* psumP;    // (rows, 16, Mp) part sums per row of the LBS share table
   float* resP;     // ([share][16] + [segment row][3 kGQ], Mp) residual-pass sums (k_residual_bm); scratch of the layout pass
-  float* gramP;    // (kGramChunks, NG, Mp) pair-Gram partial sums
+  float* gramP;    // (workgroups of k_pair_gram_bm, NG, Mp) pair-Gram partial sums
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -263,7 +264,10 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w, bool fwd_
     ws.psumP = (float*)take(lbs_rows * 16 * Mp * 4);
     ws.resP = (float*)take(std::max(res_rows, 3 * nslab) * Mp * 4);
   }
-  ws.gramP = (float*)take((size_t)32 * (NE1 - 1) * Mp * 4);  // kGramChunks x NG (<= NE) x Mp
+  {  // k_pair_gram_bm: one upper triangle per workgroup of 8 units (2 per joint + chunks of 4 pairs), NG <= NE
+    const size_t units = 2 * J + (t.pair_c3.size() + 3) / 4;
+    ws.gramP = (float*)take((units + 7) / 8 * (NE1 - 1) * Mp * 4);
+  }
   ws.jdT = (float*)take(Mp * align_up((size_t)J * sf::jd_stride(S), 64) * 4, true);
   if (w) *w = ws;
   return off;
@@ -407,12 +411,8 @@ void launch_residual_bm_s(const smplfit_handle* h, const Workspace& ws, int B, h
     hipLaunchKernelGGL((k_residual_bm<S>), share_grid(sv, Mp), dim3(64 * kBW),
                        std::max(kResidualLds, (size_t)tune().bm_lds_kb * 1024), st, d, sv, ws, B, Mp);
   if (which & 2) {
-    if constexpr (S > 10) {  // two launches over the rows of the Gramian (see k_pair_gram_bm)
-      hipLaunchKernelGGL((k_pair_gram_bm<S, 1>), dim3(kGramChunks, Mp / 64), dim3(64), 0, st, d, ws, B, Mp);
-      hipLaunchKernelGGL((k_pair_gram_bm<S, 2>), dim3(kGramChunks, Mp / 64), dim3(64), 0, st, d, ws, B, Mp);
-    } else {
-      hipLaunchKernelGGL((k_pair_gram_bm<S>), dim3(kGramChunks, Mp / 64), dim3(64), 0, st, d, ws, B, Mp);
-    }
+    const int units = 2 * d.J + (d.jt.np + kPgPairs - 1) / kPgPairs;
+    hipLaunchKernelGGL((k_pair_gram_bm<S>), dim3((units + kPgWaves - 1) / kPgWaves, Mp / 64), dim3(64 * kPgWaves), 0, st, d, ws, B, Mp);
   }
   if (which & 4)
     hipLaunchKernelGGL((k_gram_combine_bm<S>), dim3((B + 255) / 256, S + 3 + 3 * d.J + sf::ne_ng(S)), dim3(256), 0,
@@ -1353,7 +1353,9 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
       up(arows, &sv.aux_rows);
     }
     up(t.brec, &d.brec);
-    up(t.pair_c1x, &d.pair_c1x);
+    up(t.pair_E, &d.pair_E);
+    up(t.jn_start, &d.jn_start);
+    up(t.jn, &d.jn);
     up(t.pair_c2e, &d.pair_c2e);
     up(t.diag_c2e, &d.diag_c2e);
   }
