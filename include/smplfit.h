@@ -104,6 +104,7 @@ enum smplfit_table_id {
   SMPLFIT_TAB_VERTEX_PIECES = 8,   /* (npieces,5) start, count, part, used, joints: the pieces of the
                                       sorted slots the batch-major vertex kernels walk (runs of one
                                       part with at most four skinning joints)                    */
+  SMPLFIT_TAB_JOINT_PAIRS = 10,    /* (npairs,2) joints j1 < j2 that share a vertex: the units of the pair-Gram form  */
   SMPLFIT_TAB_CELL_COUNTS = 9,     /* (4) cells per instance block of the four cell tables below (empty: the
                                       model has no batch-major tables)                            */
 };

@@ -27,7 +27,7 @@ SMPLFIT_ABI_VERSION = 4  # include/smplfit.h; checked against smplfit_abi_versio
 
 TABLE_IDS = dict(
     part_assignment=0, sort_perm=1, part_type=2, fk_order=3, fk_level_start=4, adj_flag=5,
-    used_part=6, segments=7, vertex_pieces=8, cell_counts=9,
+    used_part=6, segments=7, vertex_pieces=8, cell_counts=9, joint_pairs=10,
 )
 
 # every symbol include/smplfit.h declares

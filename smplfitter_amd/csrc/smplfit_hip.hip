@@ -1472,6 +1472,7 @@ int smplfit_get_table(const smplfit_handle* h, int table_id, int32_t* dst, size_
       }
       src = &tmp;
       break;
+    case SMPLFIT_TAB_JOINT_PAIRS: src = &t.pair_j; break;
     case SMPLFIT_TAB_CELL_COUNTS:
       for (auto& st : t.shares) tmp.push_back(st.ncells);
       src = &tmp;

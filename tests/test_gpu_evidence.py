@@ -476,3 +476,19 @@ def test_bench_refuses_missing_devices():
     p = subprocess.run([sys.executable, 'bench.py', '--gpus', '64', '--steps', '1', '--warmup', '0'], cwd=ROOT,
                        capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and 'device' in (p.stderr + p.stdout)
+
+
+def test_bench_world1_rccl_gather(model_root):
+    """The RCCL leg of bench.py with ONE rank (`--collective-always`): a world-1 nccl process group, the packed result
+    rows all-gathered by `all_gather_into_tensor` on the fit's stream after every step — the same call, on the same
+    stream, that N ranks make over xGMI (the box has one GPU: this is the part of the collective path that can run here)."""
+    env = dict(os.environ, SMPLFIT_SYNTH_ROOT=model_root)
+    cmd = [sys.executable, 'bench.py', '--steps', '2', '--warmup', '1', '--batch', '512', '--no-cpu-baseline',
+           '--collective-always']
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert p.returncode == 0 and len(lines) == 1, p.stdout[-2000:] + p.stderr[-3000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 1 and out['nccl_world_size'] == 1 and out['value'] > 0
+    assert out['collective'].startswith('nccl all_gather_into_tensor')
+    assert out['roofline']['stream_bytes_per_launch'] and out['roofline']['frac_of_section8d_bytes'] > 0
