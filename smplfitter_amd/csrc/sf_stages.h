@@ -555,10 +555,16 @@ SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const doubl
   // updating one entry of the trailing triangle, instead of three syncs and a lane-0 step per column — and
   // column-oriented substitutions spread over the lanes instead of two serial triangular loops on lane 0
   // (cycle stamps, S = 10: 26 k -> 8 k of the stage's 50 k cycles).  fp64 throughout, as before.
-  double* rd = r2p;  // S: 1 / D_k (the partial sums of r2 are consumed by now)
+  // rd ALIASES r2p: the partial sums of r2 were read by the sum loop above, and the cx.sync() that opens the first
+  // column below is what orders those reads before the first write of rd[0].
+  // A pivot D_k <= 0 (a Gramian that is not positive definite: a singular system with both regularisers at 0) becomes
+  // NaN, which reaches every unknown — the failure signal of the Cholesky factorisation this replaces (sqrt of a
+  // negative number; the reference ignores cholesky_ex's info and returns what it gets, :1083).
+  double* rd = r2p;  // S: 1 / D_k
   for (int k = 0; k < S; ++k) {
     cx.sync();
-    const double rdk = 1.0 / M[k * S + k];
+    const double dk = M[k * S + k];
+    const double rdk = dk > 0.0 ? 1.0 / dk : (dk - dk) / (dk - dk);  // NaN for a non-positive pivot (0 / 0, also on a NaN pivot)
     if (cx.lane == 0) rd[k] = rdk;
     const int m = S - 1 - k;  // trailing rows i = k + 1 + a, columns j = k + 1 + b, b <= a
     SF_FOR(idx, m * m) {

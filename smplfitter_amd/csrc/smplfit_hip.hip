@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 
 #include <cstdio>
 #include <cstdlib>
@@ -322,9 +323,12 @@ struct Tuning {
   int bm_lds_kb = 0;       // SMPLFIT_BM_LDS_KB: LDS request of the two batch-major vertex passes padded to this (54: three
                            // workgroups per CU instead of four, which leaves registers / LDS for another chunk's small kernels)
 };
-Tuning g_tune;
-std::once_flag g_tune_once;
-void load_tuning() {
+// The current options: an immutable snapshot behind an atomic pointer.  smplfit_reload_options() publishes a new
+// snapshot; a launch that is reading the old one on another thread keeps a valid object (snapshots are never freed:
+// a few hundred bytes per reload).
+std::atomic<const Tuning*> g_tune{nullptr};
+std::mutex g_tune_mu;
+Tuning read_tuning() {
   Tuning t;
   auto env = [](const char* n) { return getenv(n); };
   if (const char* e = env("SMPLFIT_BM")) t.bm = e[0] != '0';
@@ -337,11 +341,23 @@ void load_tuning() {
   if (const char* e = env("SMPLFIT_LBS_LAST")) t.lbs_all_last = e[0] == 'a';
   if (const char* e = env("SMPLFIT_BM_SLOTS")) t.bm_slots = std::min(std::max(atoi(e), 256), 16384);
   if (const char* e = env("SMPLFIT_BM_LDS_KB")) t.bm_lds_kb = std::min(std::max(atoi(e), 0), 64);
-  g_tune = t;
+  return t;
+}
+void load_tuning() {
+  std::lock_guard<std::mutex> lock(g_tune_mu);
+  g_tune.store(new Tuning(read_tuning()), std::memory_order_release);
 }
 const Tuning& tune() {
-  std::call_once(g_tune_once, load_tuning);
-  return g_tune;
+  const Tuning* t = g_tune.load(std::memory_order_acquire);
+  if (!t) {
+    std::lock_guard<std::mutex> lock(g_tune_mu);
+    t = g_tune.load(std::memory_order_acquire);
+    if (!t) {
+      t = new Tuning(read_tuning());
+      g_tune.store(t, std::memory_order_release);
+    }
+  }
+  return *t;
 }
 
 // The unit-weight vertex block has two implementations:
@@ -1297,6 +1313,14 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
     // the A-stationary split kernel (Kp == 208) gives the bias row its third term in the LAST k-step, where SMPL's
     // 207 pose features put it; a model with Kp == 208 whose bias row sits elsewhere takes the fp32-MFMA GEMM
     if (sf::kGemm3 && t.Kp == 208 && sf::rp_pos(t.P, t.Kp) / 16 != kGemmKS - 1) d.gemm_exclusive = 0;
+    if (!d.gemm_exclusive && !tune().gemm_f32) {  // said once per process: every fit of this handle takes the ~3x slower GEMM
+      static std::once_flag warned;
+      const int regs_now = regs;
+      std::call_once(warned, [regs_now] {
+        std::fprintf(stderr, "smplfit: the split-bf16 posedirs GEMM is disabled for this model (kernel registers %d < 256 or a "
+                             "bias row outside the last k-step): using the fp32-MFMA GEMM (smplfit_info.gemm_vgprs)\n", regs_now);
+      });
+    }
   }
   std::vector<uint16_t>().swap(h->t.pdB2);  // the host copy of the stage images is not needed any more
   up(t.cpackA, &d.cpackA);

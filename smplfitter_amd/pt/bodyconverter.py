@@ -55,6 +55,21 @@ class BodyConverter(nn.Module):
         self._transfers = {}  # device index -> _lib.Transfer
         self._plans = {}      # device index -> _lib.ConvertPlan, or None where the fused call does not apply
 
+    # the native objects (ctypes handles) are per-process caches: a copy / pickle of the module starts without them
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state['_transfers'], state['_plans'] = {}, {}
+        return state
+
+    def __deepcopy__(self, memo):
+        import copy
+
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = {} if k in ('_transfers', '_plans') else copy.deepcopy(v, memo)
+        return new
+
     # -- native objects ----------------------------------------------------------------------------
     def _transfer(self, device: torch.device) -> Optional[_lib.Transfer]:
         if self.vertex_converter_csr is None:
@@ -157,7 +172,14 @@ class BodyConverter(nn.Module):
                 final_adjust_rots=0, out_pose_rotvecs=p(out['pose_rotvecs']), out_shape_betas=p(out['shape_betas']),
                 out_trans=p(out['trans']), out_kid_factor=p(out['kid_factor']), workspace=ws.data_ptr(),
                 workspace_bytes=ws.numel(), hip_stream=torch.cuda.current_stream(device).cuda_stream)
-            _lib.check(_lib.load().smplfit_convert_f32(plan.ptr, C.byref(args)))
+            try:
+                _lib.check(_lib.load().smplfit_convert_f32(plan.ptr, C.byref(args)))
+            except NotImplementedError:
+                # the plan was made while the batch-major kernels applied; the tuning options have been reloaded since
+                # (SMPLFIT_BM=0, SMPLFIT_GEMM=f32): forget the plan, take the forward + transfer + fit calls
+                idx = device.index if device.index is not None else torch.cuda.current_device()
+                self._plans[idx] = None
+                return None
         return out
 
     def convert_vertices(self, inp_vertices: torch.Tensor) -> torch.Tensor:

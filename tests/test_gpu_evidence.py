@@ -165,9 +165,10 @@ def test_gemm_split_precision(model_root, golden, dev, smplfit_env):
     """The posedirs contraction on the bf16 matrix cores (error-free bf16 split of both fp32 operands, three products
     per k-step + the bias row's third term, fp32 accumulate: k_posedirs_gemm_bf16x3, the default) is fp32-class at the
     vertex level: against the fp64 oracle its forward mesh is as accurate as the one computed with the fp32 MFMA
-    (SMPLFIT_GEMM=f32; gate: <= 1.5x its error + 5e-8 m, and < 2e-6 m absolute), on small and on large rotations (pose
-    features of order 1: the pose-corrective offsets, where the dropped 2^-18 terms live, are then largest), and whole
-    fits agree to the last digits."""
+    (SMPLFIT_GEMM=f32; gate: <= 1.5x its error + 5e-8 m, and < 2e-6 m absolute), on small, on large and on EXTREME
+    rotations (3 rad per component on every joint: rotation angles up to pi and beyond, pose features of order 2 — the
+    pose-corrective offsets, where the dropped 2^-18 terms live, are then as large as they get), and whole fits agree
+    to the last digits."""
     g = golden('smpl')
     kind, md = util.load_md(model_root, 'smpl', g)
     om64, _ = util.make_oracle(md, kind, np.float64)
@@ -175,7 +176,7 @@ def test_gemm_split_precision(model_root, golden, dev, smplfit_env):
     rs = np.random.RandomState(11)
     B = 48
     errs = {}
-    for scale in (0.1, 1.0):
+    for scale in (0.1, 1.0, 3.0):
         pose = (rs.randn(B, 72) * scale).astype(np.float32)
         betas = (rs.randn(B, 10) * 0.5).astype(np.float32)
         trans = rs.randn(B, 3).astype(np.float32)
@@ -186,7 +187,7 @@ def test_gemm_split_precision(model_root, golden, dev, smplfit_env):
             errs[(scale, mode)] = float(np.abs(v - ref).max())
     smplfit_env('SMPLFIT_GEMM', None)
     print('\n[gemm] max |forward - fp64| (m):', {f'{k[1]}@{k[0]}': f'{v:.2e}' for k, v in errs.items()})
-    for scale in (0.1, 1.0):
+    for scale in (0.1, 1.0, 3.0):
         assert errs[(scale, 'f32')] < 2e-6 and errs[(scale, 'bf16x3')] < 2e-6
         assert errs[(scale, 'bf16x3')] <= 1.5 * errs[(scale, 'f32')] + 5e-8, errs
     tv, tj = make_targets(m, 256, 9, dev)
@@ -200,16 +201,17 @@ def test_gemm_split_precision(model_root, golden, dev, smplfit_env):
     assert util.vertex_l2(om64, out['bf16x3'], out['f32']) < 2e-5
 
 
-@pytest.mark.parametrize('B', [300, 1024])
-def test_gemm_tiled_split_smplx(B, model_root, golden, dev, smplfit_env):
+@pytest.mark.parametrize('B,pose_scale', [(300, 0.1), (1024, 0.1), (300, 1.0)])
+def test_gemm_tiled_split_smplx(B, pose_scale, model_root, golden, dev, smplfit_env):
     """SMPL-X (K = 487): the batch-major path runs the tiled split-bf16 GEMM (k_posedirs_gemm_bf16x3_tiled, feature
     images by k_split_features); whole fits agree with the fp32-MFMA GEMM (SMPLFIT_GEMM=f32) to the last digits —
-    B = 300 leaves the second 256-instance tile mostly empty, 1024 runs as two chunks."""
+    B = 300 leaves the second 256-instance tile mostly empty, 1024 runs as two chunks; pose_scale 1.0: rotations of
+    ~1 rad per component on all 55 joints (pose features of order 1)."""
     g = golden('smplx')
     kind, md = util.load_md(model_root, 'smplx', g)
     om64, _ = util.make_oracle(md, kind, np.float64)
     m, f = get_model(model_root, 'smplx', g, dev)
-    tv, tj = make_targets(m, B, 5, dev)
+    tv, tj = make_targets(m, B, 5, dev, pose_scale=pose_scale)
     out = {}
     for mode in ('bf16x3', 'f32'):
         smplfit_env('SMPLFIT_GEMM', mode)

@@ -141,11 +141,11 @@ def test_stage_goldens(name, model_root, golden, dev):
     assert np.abs(r['vertices'][:, ::300] - g['stage.vertices0_sub']).max() < 2e-5
 
 
-def make_targets(m, B, seed, dev, noise=0.0):
+def make_targets(m, B, seed, dev, noise=0.0, pose_scale=0.1):
     """Seeded on-manifold targets, protocol of benchmark/run_benchmark.py:141-147."""
     rs = np.random.RandomState(seed)
     J = m.num_joints
-    pose = (rs.randn(B, 3 * J) * 0.1).astype(np.float32)
+    pose = (rs.randn(B, 3 * J) * pose_scale).astype(np.float32)
     betas = (rs.randn(B, 10) * 0.5).astype(np.float32)
     trans = rs.randn(B, 3).astype(np.float32)
     fw = m(t(pose, dev), t(betas, dev), t(trans, dev))
