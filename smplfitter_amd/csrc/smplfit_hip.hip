@@ -849,7 +849,10 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
       const int Mp = (int)align_up((size_t)B, 128);
       launch_gemm(d, ws, B, st, true);
       // joint rows instance-innermost for the three kernels below; AFTER the GEMM: in front of it the
-      // chunk's GEMM starts later and the chunks overlap worse (1.37 vs 1.40 M fits/s)
+      // chunk's GEMM starts later and the chunks overlap worse (1.37 vs 1.40 M fits/s).  (Round 4, measured and
+      // not kept: k_joint_stage writing ws.jdT itself — 64 waves of one XCD completing every 256-byte row with
+      // one float each — instead of this 8 us launch: 2.54 -> 2.50 M fits/s, SMPL-X 1.31 -> 1.24: the scattered
+      // stores cost the latency-bound stage more than the transpose.)
       launch_jd_transpose(d, ws, B, st);
       launch_residual_bm(h, ws, B, st);
     } else {
