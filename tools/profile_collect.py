@@ -58,10 +58,10 @@ def stats_csv(rows, path, head, chunks, warm=3):
 
 bench = json.load(open(f'{src}/bench_default.json'))
 build = bench['build']
-head = f'rocprofv3 --kernel-trace of `python bench.py --steps 10 --warmup 3 --no-cpu-baseline`, build "{build}", git HEAD see profiles/README.md'
+head = f'rocprofv3 --kernel-trace of `python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs`, build "{build}", git HEAD see profiles/README.md'
 lines = []
 for sub, name, extra, nch in (('trace1', f'{tag}_kernel_stats_chunks1.csv', 'SMPLFIT_CHUNKS=1 (4096-instance launches)', 1),
-                              ('trace2', f'{tag}_kernel_stats.csv', 'default chunking (two 2048-instance chunks on two streams)', 2)):
+                              ('trace2', f'{tag}_kernel_stats_chunks2.csv', 'SMPLFIT_CHUNKS=2 (two 2048-instance chunks on two streams)', 2)):
     rows = trace_rows(f'{src}/{sub}')
     if rows:
         lines.append(stats_csv(rows, f'{DST}/{name}', head + '; ' + extra, nch))
