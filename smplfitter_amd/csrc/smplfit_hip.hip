@@ -2036,6 +2036,96 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
   return post_launch_check();
 }
 
+#ifdef SMPLFIT_GEMM_SHARED_CU
+// Debug builds of the neighbour-interaction probe (tools/lds_probe.py): a victim that fills its LDS once and then only
+// READS it — uniform-address and per-lane addresses, 4- and 16-byte reads — checking every value; a wrong value is
+// logged with its lane, address and a second read of the same cell (transient read fault or changed LDS contents?),
+// and the whole table is verified once more at the end.
+__global__ __launch_bounds__(64) void k_lds_victim(uint32_t* __restrict__ log, int* __restrict__ nlog, int iters, int maxlog) {
+  __shared__ __attribute__((aligned(16))) uint32_t tab[2048];
+  const int lane = threadIdx.x;
+  const uint32_t salt = blockIdx.x * 977u;
+  auto val = [&](uint32_t i) { return (i * 2654435761u) ^ salt; };
+  for (int i = lane; i < 2048; i += 64) tab[i] = val(i);
+  __syncthreads();
+  volatile uint32_t* vt = tab;
+  auto report = [&](int it, int kind, uint32_t addr, uint32_t got) {
+    const uint32_t again = vt[addr];
+    const int k = atomicAdd(nlog, 1);
+    if (k < maxlog) {
+      uint32_t* r = log + (size_t)k * 8;
+      r[0] = blockIdx.x; r[1] = (uint32_t)it; r[2] = (uint32_t)lane; r[3] = (uint32_t)kind; r[4] = addr; r[5] = got;
+      r[6] = val(addr); r[7] = again;
+    }
+  };
+  for (int it = 0; it < iters; ++it) {
+    const uint32_t au = (uint32_t)(it * 7) & 2047u, al = (uint32_t)(it * 13 + lane * 5) & 2047u;
+    const uint32_t u = vt[au];                                   // uniform address, 4 bytes
+    if (u != val(au)) report(it, 0, au, u);
+    const uint32_t l = vt[al];                                   // per-lane address, 4 bytes
+    if (l != val(al)) report(it, 1, al, l);
+    const uint32_t a4 = (uint32_t)(it * 28) & 2044u;             // uniform address, 16 bytes
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 q = *reinterpret_cast<volatile u32x4*>(tab + a4);
+    if (q.x != val(a4)) report(it, 2, a4, q.x);
+    if (q.y != val(a4 + 1)) report(it, 2, a4 + 1, q.y);
+    if (q.z != val(a4 + 2)) report(it, 2, a4 + 2, q.z);
+    if (q.w != val(a4 + 3)) report(it, 2, a4 + 3, q.w);
+    const uint32_t b4 = ((uint32_t)(it * 4 + lane * 12)) & 2044u;  // per-lane address, 16 bytes
+    const u32x4 p = *reinterpret_cast<volatile u32x4*>(tab + b4);
+    if (p.x != val(b4)) report(it, 3, b4, p.x);
+    if (p.w != val(b4 + 3)) report(it, 3, b4 + 3, p.w);
+  }
+  for (int i = lane; i < 2048; i += 64)
+    if (vt[i] != val(i)) report(-1, 4, (uint32_t)i, vt[i]);     // the contents at the end
+}
+
+// Second victim: packed-fp32 FMAs whose operands are uniform-address 16-byte LDS reads (the form of the round-2 / 3
+// victims); every value is a small integer, so the sums are exact and must equal the solo run bit for bit.
+__global__ __launch_bounds__(64) void k_lds_victim_fma(float* __restrict__ out, int iters, int rewrite) {
+  __shared__ __attribute__((aligned(16))) float tab[2048];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 2048; i += 64) tab[i] = (float)((i * 5 + blockIdx.x) % 7);
+  __syncthreads();
+  f2 acc[16];
+  for (int k = 0; k < 16; ++k) acc[k] = mk2(0.f, 0.f);
+  const f2 v = mk2((float)(lane % 3), (float)((lane + 1) % 3));
+  for (int it = 0; it < iters; ++it) {
+    const float4* row = reinterpret_cast<const float4*>(tab) + ((it * 8) & 511);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float4 c = row[u];  // uniform address: broadcast read
+      acc[2 * u] += mk2(c.x, c.y) * v;
+      acc[2 * u + 1] += mk2(c.z, c.w) * v;
+    }
+    if (rewrite && (it & 15) == 15) {  // the victim also rewrites its table (same values), as a double-buffered kernel does
+      __syncthreads();
+      for (int i = lane; i < 2048; i += 64) tab[i] = (float)((i * 5 + blockIdx.x) % 7);
+      __syncthreads();
+    }
+    if ((it & 63) == 63)
+      for (int k = 0; k < 16; ++k) {
+        acc[k].x = acc[k].x > 4.0e5f ? acc[k].x - 4.0e5f : acc[k].x;
+        acc[k].y = acc[k].y > 4.0e5f ? acc[k].y - 4.0e5f : acc[k].y;
+      }
+  }
+  for (int k = 0; k < 16; ++k) {
+    out[((size_t)blockIdx.x * 32 + 2 * k) * 64 + lane] = acc[k].x;
+    out[((size_t)blockIdx.x * 32 + 2 * k + 1) * 64 + lane] = acc[k].y;
+  }
+}
+
+int smplfit_debug_lds_victim_fma(void* stream, int nwg, int iters, int rewrite, float* out) {
+  hipLaunchKernelGGL(k_lds_victim_fma, dim3(nwg), dim3(64), 0, (hipStream_t)stream, out, iters, rewrite);
+  return post_launch_check();
+}
+
+int smplfit_debug_lds_victim(void* stream, int nwg, int iters, uint32_t* log, int* nlog, int maxlog) {
+  hipLaunchKernelGGL(k_lds_victim, dim3(nwg), dim3(64), 0, (hipStream_t)stream, log, nlog, iters, maxlog);
+  return post_launch_check();
+}
+#endif
+
 #ifdef SMPLFIT_WAVE_STAMPS
 // debug builds: the stamps of the last k_residual_bm launch (n waves x 5 values), see kernels_bm.inc
 int smplfit_debug_wave_stamps(unsigned long long* dst, int n) {
