@@ -105,18 +105,23 @@ enum smplfit_table_id {
                                       sorted slots the batch-major vertex kernels walk (runs of one
                                       part with at most four skinning joints)                    */
   SMPLFIT_TAB_JOINT_PAIRS = 10,    /* (npairs,2) joints j1 < j2 that share a vertex: the units of the pair-Gram form  */
-  SMPLFIT_TAB_CELL_COUNTS = 9,     /* (4) cells per instance block of the four cell tables below (empty: the
-                                      model has no batch-major tables)                            */
+  SMPLFIT_TAB_CELL_COUNTS = 9,     /* (8) cells per instance block of the cell tables below: the four kinds'
+                                      coarse tables, then their fine ones (empty: the model has no
+                                      batch-major tables)                                          */
 };
 int smplfit_get_table(const smplfit_handle* h, int table_id, int32_t* dst, size_t cap, size_t* n);
 
 /* Cell tables of the batch-major vertex kernels (test access): `kind` 0 residual pass, 1 part sums over every slot,
- * 2 over the used parts, 3 over the adjustable parts; `what` 0 piece_start (ncells + 1), 1 piece records
+ * 2 over the used parts, 3 over the adjustable parts; 4-7: the FINE tables of the same kinds, which batches of up
+ * to SMPLFIT_FINE_B (default 768) instances walk — eight times the cells, a short walk per wave; the rows of partial
+ * sums differ, so a small batch agrees with a large one to rounding, not bit for bit.
+ * `what` 0 piece_start (ncells + 1), 1 piece records
  * (npieces + 1, 12): count, joints[4], local slots[4], first slot, row closed behind the piece (-1 none), kind 0:
  * joints of that row | (cell + 1) << 8 behind the last piece of a cell; 2 the rows: part per row (kinds 1-3) or
  * (nrows, 12) joint of every local slot, -1 unused (kind 0). */
 int smplfit_get_share_table(const smplfit_handle* h, int kind, int what, int32_t* dst, size_t cap, size_t* n);
-/* Cells per wave a launch over `batch` instances picks for `kind` (with the current tuning options). */
+/* Cells per wave a launch over `batch` instances picks for `kind` 0-3 — of the fine table when the batch takes it
+ * (with the current tuning options). */
 int smplfit_pick_share_mult(const smplfit_handle* h, int kind, int batch);
 
 /* Bytes of device workspace a call on `batch` instances needs (256-byte aligned base). */

@@ -21,7 +21,7 @@ struct PieceRun {  // a whole or split piece on its way into a share
 };
 int piece_cost(int count) { return count + (count & 1) + kPieceCost; }
 
-void build_share_table(const HostTables& t, int kind, ShareTable& out) {
+void build_share_table(const HostTables& t, int kind, ShareTable& out, int cell_steps, int cell_cap) {
   out = ShareTable();
   std::vector<PieceRun> dom;
   long total = 0;
@@ -33,7 +33,7 @@ void build_share_table(const HostTables& t, int kind, ShareTable& out) {
   }
   // cells of ~75+ steps, a power of two of them (so that the share counts of power-of-two batches fill whole rounds)
   int ns = 8;
-  while (ns < 256 && (long)ns * 2 * SMPLFIT_CELL_STEPS <= total) ns *= 2;
+  while (ns < cell_cap && (long)ns * 2 * cell_steps <= total) ns *= 2;
   // deal the domain to ns cells of equal cost: whole pieces while they fit, then the head of the next one (an even
   // number of vertices, so that a split adds no padding step).  Every boundary that splits a piece costs the piece
   // overhead once more: the budget of a cell counts it for the boundaries still ahead.
@@ -160,9 +160,10 @@ void build_share_table(const HostTables& t, int kind, ShareTable& out) {
 void build_share_tables(HostTables& t) {
   t.shares.clear();
   if (t.vpieces.empty()) return;
-  t.shares.resize(kShareKinds);
-  for (int k = 0; k < kShareKinds; ++k) {
-    build_share_table(t, k, t.shares[k]);
+  t.shares.resize(2 * kShareKinds);
+  for (int k = 0; k < 2 * kShareKinds; ++k) {
+    if (k < kShareFine) build_share_table(t, k, t.shares[k], SMPLFIT_CELL_STEPS, SMPLFIT_CELL_CAP);
+    else build_share_table(t, k - kShareFine, t.shares[k], kFineCellSteps, kFineCellCap);
     if (t.shares[k].ncells == 0) {  // a domain too small for its cells: the model stays on the wave-per-instance kernels
       t.shares.clear();
       return;

@@ -56,9 +56,30 @@ constexpr int kGroupJoints = 12;  // local joint slots of a residual SEGMENT (mo
 #ifndef SMPLFIT_BM_WAVES
 #define SMPLFIT_BM_WAVES 4
 #endif
+#ifndef SMPLFIT_CELL_CAP
+#define SMPLFIT_CELL_CAP 256  // at most this many cells
+#endif
 #ifndef SMPLFIT_CELL_STEPS
 #define SMPLFIT_CELL_STEPS 75  // a cell holds at least this many steps (and fewer than twice as many)
 #endif
+// SMALL BATCHES take a second, FINE set of the same tables.  Up to a few hundred instances a vertex pass is one round
+// of lonely waves — one per SIMD at most — and its duration is the WALK of a cell: ~110 steps at the issue rate of a
+// single wave (0.37 us a step: 40 us of residual pass at B = 32, where 0.2 us would move the bytes).  The fine tables
+// deal the same domains to cells of kFineCellSteps+ steps (512 cells for the SMPL-shaped model: a 10 us walk); their
+// eight times as many rows of partial sums — more bytes than the streams themselves — are why the large batches keep
+// the coarse ones.  The two regimes add the partial sums in different orders: an instance's result is independent of
+// its batch WITHIN a regime (batches up to kFineMaxBatch / above), and agrees to rounding across.  Measured (ms per
+// default fit, coarse -> fine): B = 32 0.57 -> 0.36, 256 0.61 -> 0.40, 512 0.65 -> 0.50, 768 0.70 -> 0.60, 1024 0.74 -> 0.72
+// (SMPL-X-shaped: 0.93 -> 0.77, 1.04 -> 0.87, 1.09 -> 0.99, 1.23 -> 1.20, 1.28 -> 1.34).
+#ifndef SMPLFIT_FINE_CELL_STEPS
+#define SMPLFIT_FINE_CELL_STEPS 12
+#endif
+constexpr int kFineCellSteps = SMPLFIT_FINE_CELL_STEPS;
+constexpr int kFineCellCap = 1024;
+#ifndef SMPLFIT_FINE_MAX_B
+#define SMPLFIT_FINE_MAX_B 768
+#endif
+constexpr int kFineMaxBatch = SMPLFIT_FINE_MAX_B;  // (workspace sizes up to this batch cover the fine rows)
 #ifndef SMPLFIT_PIECE_COST
 #define SMPLFIT_PIECE_COST 3
 #endif
@@ -75,7 +96,8 @@ enum ShareKind : int {
   kShareLbsUsed = 2,   // the slots of the used parts (bodyfitter.py:109-114)
   kShareLbsAdj = 3,    // the slots of the adjustable parts only: the LAST part sums of a fit feed the dependent
                        // refinement alone, which reads them at the adjustable parts (bodyfitter.py:1505-1517)
-  kShareKinds = 4
+  kShareKinds = 4,
+  kShareFine = 4  // HostTables::shares[kShareFine + kind]: the fine table of a kind
 };
 struct ShareTable {
   int ncells = 0, nrows = 0, max_cost = 0;
@@ -169,7 +191,7 @@ struct HostTables {
   std::vector<Segment> gtiles;
   // batch-major kernels: the pieces of the sorted slots and the cell tables cut from them, one per ShareKind
   std::vector<VertexPiece> vpieces;
-  std::vector<ShareTable> shares;  // (kShareKinds), empty when the model has no batch-major tables
+  std::vector<ShareTable> shares;  // (2 kShareKinds: coarse, fine), empty when the model has no batch-major tables
   // the batch-major pair-Gram kernel reads rows of shape values as aligned register PAIRS: its copies of the
   // constants have the y axis padded to an even length SE = S rounded up to 2 (the padding is zero)
   std::vector<float> pair_E;     // (np, 9 [a a'], ng_pad()) symmetrised pair_c1 over the upper triangle (i <= i2, row-major)

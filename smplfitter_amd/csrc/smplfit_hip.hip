@@ -88,6 +88,7 @@ struct ShareView {
   const int32_t *aux_start, *aux_rows;
   int ncells, nrows;
   int mult;  // cells per wave: share s walks the cells [s * mult, (s + 1) * mult)
+  int fine;  // the fine table of its kind (small batches): the combine kernels split the rows over waves
 };
 
 }  // namespace
@@ -159,10 +160,39 @@ struct DevCtx {
   __device__ __forceinline__ void sync() const { __syncthreads(); }
   __device__ __forceinline__ float sum_to_last(float v) const { return wave_sum_last(v); }  // (n == 64: one wave)
 #ifdef SMPLFIT_STAGE_STAMPS
+#ifndef SMPLFIT_STAMP_B
+#define SMPLFIT_STAMP_B 1000  // the instance whose stamps are printed
+#endif
   long long t[12] = {};
   __device__ __forceinline__ void stamp(int k) { t[k] = __builtin_readcyclecounter(); }
 #endif
 };
+
+// the same over each half of the wave: the half totals land in lanes 31 and 63
+__device__ __forceinline__ float half_sum_last(float v) {
+  v = dpp_step<0x111, 0xf>(v);
+  v = dpp_step<0x112, 0xf>(v);
+  v = dpp_step<0x114, 0xf>(v);
+  v = dpp_step<0x118, 0xf>(v);
+  v = dpp_step<0x142, 0xa>(v);
+  return v;
+}
+
+// Small-model form of the per-instance stages (J <= 32): TWO instances per wave, 32 lanes each.  Those stages are
+// VALU-issue bound and most of their loops run over the joints, so a 24-joint model leaves 40 of the 64 lanes idle;
+// with two instances per wave the same instructions serve both.  The barrier is the workgroup's (both halves run the
+// same uniform control flow), the scratch of half h starts at h * <stage scratch>.
+struct DevCtxHalf {
+  int lane, n;
+  __device__ __forceinline__ void sync() const { __syncthreads(); }
+  __device__ __forceinline__ float sum_to_last(float v) const { return half_sum_last(v); }
+#ifdef SMPLFIT_STAGE_STAMPS
+  long long t[12] = {};
+  __device__ __forceinline__ void stamp(int k) { t[k] = __builtin_readcyclecounter(); }
+#endif
+};
+template <int N> struct StageCtx { using type = DevCtx; };
+template <> struct StageCtx<32> { using type = DevCtxHalf; };
 
 // Per-call workspace carve (device pointers).
 struct Workspace {
@@ -255,9 +285,13 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w, bool fwd_
   ws.vpT = (float*)take(Mp * 3 * Vp * 4, true);
   ws.tT = (float*)take(Mp * 3 * Vp * 4);
   {
+    // rows of partial sums: the coarse tables', and the fine tables' as well for a batch that may take them (whatever
+    // SMPLFIT_FINE_B says at the time of the call)
     size_t lbs_rows = 0, res_rows = 0;
     for (size_t k = 0; k < t.shares.size(); ++k) {
-      if (k == sf::kShareResidual) res_rows = (size_t)t.shares[k].ncells * 16 + (size_t)t.shares[k].nrows * 3 * sf::kGroupJoints;
+      if ((int)k >= sf::kShareFine && B > sf::kFineMaxBatch) break;
+      if ((int)k % sf::kShareKinds == sf::kShareResidual)
+        res_rows = std::max(res_rows, (size_t)t.shares[k].ncells * 16 + (size_t)t.shares[k].nrows * 3 * sf::kGroupJoints);
       else lbs_rows = std::max(lbs_rows, (size_t)t.shares[k].nrows);
     }
     // (the layout kernel's slab sums use ws.resP as scratch: 3 rows per slab)
@@ -319,6 +353,8 @@ struct Tuning {
   int gemm_nchunk = 0;     // SMPLFIT_GEMM_NCHUNK: column-tile chunks of the split-bf16 GEMM (0 = automatic)
   int gemm_lds_kb = 0;     // SMPLFIT_GEMM_LDS_KB: LDS request of the fp32 A-stationary GEMM (occupancy experiments)
   bool lbs_all_last = false;  // SMPLFIT_LBS_LAST=all: the last part sums of a fit over every used part (A/B of the adjustable-parts pass)
+  int stage_half_b = 2048; // SMPLFIT_STAGE_HALF_B: smallest batch whose per-instance stages run two instances per wave (J <= 32)
+  int fine_b = sf::kFineMaxBatch;  // SMPLFIT_FINE_B: largest batch that takes the fine cell tables (0: none; at most sf::kFineMaxBatch)
   int bm_slots = 4096;     // SMPLFIT_BM_SLOTS: resident waves a batch-major vertex pass is dealt for (share-count choice)
   int bm_lds_kb = 0;       // SMPLFIT_BM_LDS_KB: LDS request of the two batch-major vertex passes padded to this (54: three
                            // workgroups per CU instead of four, which leaves registers / LDS for another chunk's small kernels)
@@ -339,6 +375,8 @@ Tuning read_tuning() {
   if (const char* e = env("SMPLFIT_GEMM_NCHUNK")) t.gemm_nchunk = std::max(1, atoi(e));
   if (const char* e = env("SMPLFIT_GEMM_LDS_KB")) t.gemm_lds_kb = atoi(e);
   if (const char* e = env("SMPLFIT_LBS_LAST")) t.lbs_all_last = e[0] == 'a';
+  if (const char* e = env("SMPLFIT_FINE_B")) t.fine_b = std::min(std::max(atoi(e), 0), sf::kFineMaxBatch);
+  if (const char* e = env("SMPLFIT_STAGE_HALF_B")) t.stage_half_b = std::max(atoi(e), 1);
   if (const char* e = env("SMPLFIT_BM_SLOTS")) t.bm_slots = std::min(std::max(atoi(e), 256), 16384);
   if (const char* e = env("SMPLFIT_BM_LDS_KB")) t.bm_lds_kb = std::min(std::max(atoi(e), 0), 64);
   return t;
@@ -389,13 +427,20 @@ void launch_jd_transpose(const DevModel& d, const Workspace& ws, int B, hipStrea
 }
 
 // The cell table a batch-major vertex pass of `kind` over B instances runs on, with its multiplier (sf::pick_share_mult).
+// the table a launch over B instances walks: the fine one up to SMPLFIT_FINE_B instances (sf_tables.h)
+int share_index(int kind, int B) { return kind + (B <= tune().fine_b ? sf::kShareFine : 0); }
 ShareView share_view(const smplfit_handle* h, int kind, int B) {
-  const int nblocks = (int)align_up((size_t)B, 128) / 64;
-  ShareView sv = h->views[kind];
-  sv.mult = sf::pick_share_mult(h->t, kind, nblocks, tune().bm_slots);
+  const int nblocks = (int)align_up((size_t)B, 128) / 64, idx = share_index(kind, B);
+  ShareView sv = h->views[idx];
+  sv.fine = idx >= sf::kShareFine;
+  sv.mult = sf::pick_share_mult(h->t, idx, nblocks, tune().bm_slots);
   return sv;
 }
 dim3 share_grid(const ShareView& sv, int Mp) { return dim3(Mp / 64, sv.ncells / sv.mult / kBW); }
+void launch_psum_combine(const DevModel& d, const ShareView& sv, const Workspace& ws, int B, int Mp, hipStream_t st) {
+  if (sv.fine) hipLaunchKernelGGL(k_psum_combine_split<8>, dim3(Mp / 64, d.J), dim3(64 * 8), 0, st, d, sv, ws, B, Mp);
+  else hipLaunchKernelGGL(k_psum_combine, dim3((B + 255) / 256, d.J), dim3(256), 0, st, d, sv, ws, B, Mp);
+}
 
 // part sums of the centred targets against the template + their combine (the first rotation estimate)
 void launch_template_partsum_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStream_t st) {
@@ -403,7 +448,7 @@ void launch_template_partsum_bm(const smplfit_handle* h, const Workspace& ws, in
   const int Mp = (int)align_up((size_t)B, 128);
   const ShareView sv = share_view(h, sf::kShareLbsUsed, B);
   hipLaunchKernelGGL(k_template_partsum_bm, share_grid(sv, Mp), dim3(64 * kBW), 0, st, d, sv, ws, B, Mp);
-  hipLaunchKernelGGL(k_psum_combine, dim3((B + 255) / 256, d.J), dim3(256), 0, st, d, sv, ws, B, Mp);
+  launch_psum_combine(d, sv, ws, B, Mp, st);
 }
 
 // One-pass target layout of the batch-major path (k_layout_targets, k_mean_finish, k_template_partsum_bm):
@@ -430,7 +475,10 @@ void launch_residual_bm_s(const smplfit_handle* h, const Workspace& ws, int B, h
     const int units = 2 * d.J + (d.jt.np + kPgPairs - 1) / kPgPairs;
     hipLaunchKernelGGL((k_pair_gram_bm<S>), dim3((units + kPgWaves - 1) / kPgWaves, Mp / 64), dim3(64 * kPgWaves), 0, st, d, ws, B, Mp);
   }
-  if (which & 4)
+  if ((which & 4) && sv.fine)
+    hipLaunchKernelGGL((k_gram_combine_split<S, 16>), dim3(Mp / 64, S + 3 + 3 * d.J + sf::ne_ng(S)), dim3(64 * 16), 0,
+                       st, d, sv, ws, B, Mp);
+  else if (which & 4)
     hipLaunchKernelGGL((k_gram_combine_bm<S>), dim3((B + 255) / 256, S + 3 + 3 * d.J + sf::ne_ng(S)), dim3(256), 0,
                        st, d, sv, ws, B, Mp);
 }
@@ -458,7 +506,7 @@ void launch_lbs_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStrea
       hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp);
     }
   }
-  hipLaunchKernelGGL(k_psum_combine, dim3((B + 255) / 256, d.J), dim3(256), 0, st, d, sv, ws, B, Mp);
+  launch_psum_combine(d, sv, ws, B, Mp, st);
 }
 
 template <int S, int KW>
@@ -663,6 +711,42 @@ size_t joint_lds(const DevModel& d, int kind = 0) {
 }
 size_t solve_lds(const DevModel& d) { return (size_t)sf::solve_scratch_floats(d.S) * 4; }
 
+// The per-instance stages run two instances per wave (DevCtxHalf) when the model's joints fit 32 lanes and the batch
+// fills the chip either way (below ~2 workgroups per CU the one-instance form is the faster one: B = 256 0.416 vs
+// 0.403 M fits/s; B = 4096 2.55 -> 2.59, 32768 2.68 -> 2.70).  A half-wave sum adds lanes 0-31 in the order the
+// wave sum does; loops longer than 32 split differently (tests/test_gpu_parity.py::test_stage_half runs both forms).
+// SMPLFIT_STAGE_HALF (compile time) masks it per stage: 1 joint stage, 2 solve, 4 refinement.
+#ifndef SMPLFIT_STAGE_HALF
+#define SMPLFIT_STAGE_HALF 7
+#endif
+inline bool stage_half(const DevModel& d, int bit, int B) {
+  return (SMPLFIT_STAGE_HALF & bit) && d.J <= 32 && B >= tune().stage_half_b;
+}
+
+void launch_joint_stage(const DevModel& d, JointStageArgs ja, const Workspace& ws, int B, hipStream_t st) {
+  ja.B = B;
+  if (stage_half(d, 1, B))
+    hipLaunchKernelGGL(k_joint_stage<32>, dim3((B + 1) / 2), dim3(64), 2 * joint_lds(d), st, d, ja, ws);
+  else
+    hipLaunchKernelGGL(k_joint_stage<64>, dim3(B), dim3(64), joint_lds(d), st, d, ja, ws);
+}
+void launch_refine(const DevModel& d, RefineArgs ra, const Workspace& ws, int B, hipStream_t st) {
+  ra.B = B;
+  if (stage_half(d, 4, B))
+    hipLaunchKernelGGL(k_refine_epilogue<32>, dim3((B + 1) / 2), dim3(64), 2 * joint_lds(d, 1), st, d, ra, ws);
+  else
+    hipLaunchKernelGGL(k_refine_epilogue<64>, dim3(B), dim3(64), joint_lds(d, 1), st, d, ra, ws);
+}
+void launch_shape_solve(const DevModel& d, const Workspace& ws, int B, hipStream_t st, float beta_reg, float beta_reg2,
+                        float kid_reg, int pair_form, int use_ref, int mode = 0) {
+  if (stage_half(d, 2, B))
+    hipLaunchKernelGGL(k_shape_solve<32>, dim3((B + 1) / 2), dim3(64), 2 * solve_lds(d), st, d, ws, B, beta_reg,
+                       beta_reg2, kid_reg, pair_form, use_ref, mode);
+  else
+    hipLaunchKernelGGL(k_shape_solve<64>, dim3(B), dim3(64), solve_lds(d), st, d, ws, B, beta_reg, beta_reg2,
+                       kid_reg, pair_form, use_ref, mode);
+}
+
 int post_launch_check() {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(SMPLFIT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
@@ -735,16 +819,13 @@ int enqueue_solve(const DevModel& d, const Workspace& ws, int B, const FitOption
     hipLaunchKernelGGL(k_shape_solve_scaled, dim3(B), dim3(64), lds, st, d, ws, sa);
   } else if (o.share_beta) {  // assemble per instance, sum over the batch, solve the sum + own translation
     const int NC = d.S * d.S + d.S;
-    hipLaunchKernelGGL(k_shape_solve, dim3(B), dim3(64), solve_lds(d), st, d, ws, o.beta_reg,
-                       o.beta_reg2, o.kid_reg, pair_in, 0, 1, B);
+    launch_shape_solve(d, ws, B, st, o.beta_reg, o.beta_reg2, o.kid_reg, pair_in, 0, 1);
     hipLaunchKernelGGL(k_share_reduce, dim3(1), dim3(512), 0, st, ws, B, NC);
     if (o.share_allreduce && o.share_allreduce(o.share_user, ws.cen + (size_t)B * NC, NC, (void*)st) != 0)
       return fail(SMPLFIT_ERR_HIP, "the share_allreduce callback failed");
-    hipLaunchKernelGGL(k_shape_solve, dim3(B), dim3(64), solve_lds(d), st, d, ws, o.beta_reg,
-                       o.beta_reg2, o.kid_reg, pair_in, 0, 2, B);
+    launch_shape_solve(d, ws, B, st, o.beta_reg, o.beta_reg2, o.kid_reg, pair_in, 0, 2);
   } else {
-    hipLaunchKernelGGL(k_shape_solve, dim3(B), dim3(64), solve_lds(d), st, d, ws, o.beta_reg,
-                       o.beta_reg2, o.kid_reg, pair_in, use_ref);
+    launch_shape_solve(d, ws, B, st, o.beta_reg, o.beta_reg2, o.kid_reg, pair_in, use_ref);
   }
   return 0;
 }
@@ -835,7 +916,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     ja.rj = ws.rjreg;
     ja.rj_shared = 1;
   }
-  if (on(0)) hipLaunchKernelGGL(k_joint_stage, dim3(B), dim3(64), joint_lds(d), st, d, ja, ws);
+  if (on(0)) launch_joint_stage(d, ja, ws, B, st);
   if (o.rotations_only) {
     if (on(0)) hipLaunchKernelGGL(k_copy, dim3(256), dim3(256), 0, st, ws.G, orient, (size_t)B * d.J * 9);
     return post_launch_check();
@@ -890,7 +971,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     ja.rj = joints ? ws.rjoints : ws.rjreg;
     ja.rj_shared = 0;
     ja.Gprev = ws.G;
-    if (pb) hipLaunchKernelGGL(k_joint_stage, dim3(B), dim3(64), joint_lds(d), st, d, ja, ws);
+    if (pb) launch_joint_stage(d, ja, ws, B, st);
   }
   if (!on(1 + 2 * o.num_iter)) return post_launch_check();
   RefineArgs ra{};
@@ -912,7 +993,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     if (o.scale_out)
       hipLaunchKernelGGL(k_copy, dim3(16), dim3(256), 0, st, ws.scale, o.scale_out, (size_t)B);
   }
-  hipLaunchKernelGGL(k_refine_epilogue, dim3(B), dim3(64), joint_lds(d, 1), st, d, ra, ws);
+  launch_refine(d, ra, ws, B, st);
   return post_launch_check();
 }
 
@@ -967,7 +1048,7 @@ int run_fit_known_shape(const smplfit_handle* h, const float* betas, int nb, con
       hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(64), 0, st, d, ws.rverts, ws.rjreg);
     if (it == o.num_iter) break;
     ja.rj = joints ? ws.rjoints : ws.rjreg;
-    hipLaunchKernelGGL(k_joint_stage, dim3(B), dim3(64), joint_lds(d), st, d, ja, ws);
+    launch_joint_stage(d, ja, ws, B, st);
     fa.pose = nullptr;
     fa.glob = ws.G;
   }
@@ -992,7 +1073,7 @@ int run_fit_known_shape(const smplfit_handle* h, const float* betas, int nb, con
   ra.orient = orient;
   ra.rel = rel;
   ra.scaled = o.scale_fit;
-  hipLaunchKernelGGL(k_refine_epilogue, dim3(B), dim3(64), joint_lds(d, 1), st, d, ra, ws);
+  launch_refine(d, ra, ws, B, st);
   return post_launch_check();
 }
 
@@ -1054,15 +1135,16 @@ int chunk_count(const sf::HostTables& t) {
   return std::min(c > 0 ? c : (t.J > 32 ? 2 : 1), kMaxChunks);
 }
 int chunk_plan_n(int n, int batch, int* sizes) {
-  while (n > 1 && batch < n * 512) --n;  // keep every chunk >= 512 instances
-  const int per = ((batch + n - 1) / n + 127) / 128 * 128;
-  int left = batch, k = 0;
-  while (left > 0 && k < kMaxChunks) {
-    sizes[k] = left < per ? left : per;
-    left -= sizes[k];
-    ++k;
-  }
-  return k;
+  // every chunk at least 896 instances (128 above sf::kFineMaxBatch): the chunks of a call all walk the coarse cell
+  // tables, and which tables a call takes depends on its batch alone (sf_tables.h).  Chunks are multiples of 128
+  // instances, the last one takes the remainder.
+  constexpr int kMinChunk = (sf::kFineMaxBatch / 128 + 1) * 128;
+  static_assert(kMinChunk > sf::kFineMaxBatch && kMinChunk % 128 == 0, "chunks stay on the coarse tables");
+  while (n > 1 && batch < n * kMinChunk) --n;
+  const int per = batch / n / 128 * 128;
+  for (int k = 0; k + 1 < n; ++k) sizes[k] = per;
+  sizes[n - 1] = batch - (n - 1) * per;
+  return n;
 }
 int chunk_plan(const sf::HostTables& t, int batch, int* sizes) { return chunk_plan_n(chunk_count(t), batch, sizes); }
 
@@ -1174,7 +1256,11 @@ int fit_impl(const smplfit_handle* h, const smplfit_fit_args* args, const Conver
   // after the other, the second chunk's first kernel waits for the host to get through the ~30 launches of the
   // first.  (Measured and not kept, round 4: a deliberate offset between the chunks — chunk c starting when chunk
   // c - 1 has finished k phases, so that the bandwidth-bound kernels of one meet the latency-bound ones of the other:
-  // 2.37 M fits/s without, 2.23 / 2.19 / 2.10 with k = 1 / 2 / 3: the offset is paid again at the join of every call.)
+  // 2.37 M fits/s without, 2.23 / 2.19 / 2.10 with k = 1 / 2 / 3: the offset is paid again at the join of every call.
+  // Nor an enforced anti-phase: a "bandwidth token" of events that orders the vertex sections (layout, GEMM + residual,
+  // LBS) of all chunks into one sequence, so that a chunk's per-instance stages run beside another chunk's vertex
+  // section: 2.56 -> 2.15 M fits/s with two chunks, 1.75 / 1.51 with three / four (SMPL-X 1.34 -> 1.19): every
+  // cross-queue event wait costs ~25 us of idle queue, twelve of them per fit.)
   std::lock_guard<std::mutex> lock(h->mu);
   SF_HIP_TRY(hipEventRecord(h->ev_fork, st));
   const int nphase = 2 + 2 * num_iter;
@@ -1351,7 +1437,7 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
     }
     // the share tables of the batch-major vertex kernels
     d.bm_tables = t.shares.empty() ? 0 : 1;
-    h->views.assign(t.shares.size(), ShareView{});
+    h->views.assign(t.shares.size(), ShareView{});  // (coarse, fine) x kinds
     for (size_t i = 0; i < t.shares.size(); ++i) {
       const sf::ShareTable& stb = t.shares[i];
       ShareView& sv = h->views[i];
@@ -1518,15 +1604,15 @@ int smplfit_get_share_table(const smplfit_handle* h, int kind, int what, int32_t
     return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_get_share_table: unknown kind / table (or a model without batch-major tables)");
   const sf::ShareTable& st = t.shares[kind];
   const std::vector<int32_t>* src =
-      what == 0 ? &st.piece_start : what == 1 ? &st.pieces : (kind == sf::kShareResidual ? &st.row_joints : &st.row_part);
+      what == 0 ? &st.piece_start : what == 1 ? &st.pieces : (kind % sf::kShareKinds == sf::kShareResidual ? &st.row_joints : &st.row_part);
   *n = src->size();
   if (dst) std::memcpy(dst, src->data(), std::min(cap, src->size()) * sizeof(int32_t));
   return SMPLFIT_OK;
 }
 
 int smplfit_pick_share_mult(const smplfit_handle* h, int kind, int batch) {
-  if (!h || kind < 0 || kind >= (int)h->t.shares.size() || batch <= 0) return -1;
-  return sf::pick_share_mult(h->t, kind, (int)align_up((size_t)batch, 128) / 64, tune().bm_slots);
+  if (!h || h->t.shares.empty() || kind < 0 || kind >= sf::kShareKinds || batch <= 0) return -1;
+  return sf::pick_share_mult(h->t, share_index(kind, batch), (int)align_up((size_t)batch, 128) / 64, tune().bm_slots);
 }
 
 size_t smplfit_workspace_bytes(const smplfit_handle* h, int batch) {
@@ -1743,7 +1829,7 @@ int smplfit_shape_solve_ex_f32(const smplfit_handle* h, const smplfit_shape_solv
   ja.joint_block_weighted = eff_j ? 1 : 0;
   ja.vertex_sa_closed_form = eff_v ? 0 : 1;
   if (!joints) hipMemsetAsync(ws.tjreg, 0, (size_t)batch * d.J * 3 * 4, st);
-  hipLaunchKernelGGL(k_joint_stage, dim3(batch), dim3(64), joint_lds(d), st, d, ja, ws);
+  launch_joint_stage(d, ja, ws, batch, st);
   launch_gemm(d, ws, batch, st);
 #define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, batch, eff_v, st)
   SF_DISPATCH_SKW(d, SF_CALL_ACCUM);
@@ -1980,8 +2066,7 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
         return 0;
       }
       case SMPLFIT_KERNEL_SHAPE_SOLVE:
-        hipLaunchKernelGGL(k_shape_solve, dim3(batch), dim3(64), solve_lds(d), st, d, ws, 1.0f, 0.0f, 1.0f,
-                           use_pair_form() ? 1 : 0, 0);
+        launch_shape_solve(d, ws, batch, st, 1.0f, 0.0f, 1.0f, use_pair_form() ? 1 : 0, 0);
         return 0;
       case SMPLFIT_KERNEL_LBS_PARTSUM: {
         if (bm) {
@@ -2006,7 +2091,7 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
     if (nopre) return 0;
     if (kernel_id == SMPLFIT_KERNEL_SHAPE_ACCUM) launch_gemm(d, ws, batch, st, bm);
     if (kernel_id == SMPLFIT_KERNEL_LBS_PARTSUM && bm)
-      hipLaunchKernelGGL(k_shape_solve, dim3(batch), dim3(64), solve_lds(d), st, d, ws, 1.0f, 0.0f, 1.0f, 1, 0);
+      launch_shape_solve(d, ws, batch, st, 1.0f, 0.0f, 1.0f, 1, 0);
     if (kernel_id == SMPLFIT_KERNEL_LBS_PARTSUM && !bm) {
 #define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, batch, false, st)
       SF_DISPATCH_SKW(d, SF_CALL_ACCUM);

@@ -108,15 +108,17 @@ def check_share_tables(h, of, md, perm, V, plain=True):
     """Every cell table deals its domain (all slots / used parts / adjustable parts) exactly once to its cells, in
     cells of nearly equal cost, and its rows say where the partial sums go."""
     ncells = h.table('cell_counts')
-    assert len(ncells) == 4 and all(n >= 8 and n & (n - 1) == 0 for n in ncells)  # powers of two
+    assert len(ncells) == 8 and all(n >= 8 and n & (n - 1) == 0 for n in ncells)  # powers of two; (coarse, fine) x 4 kinds
+    assert all(ncells[4 + k] >= ncells[k] for k in range(4))
     slot_part = of.part[perm[:V]]
     domains = {0: np.ones(V, bool), 1: np.ones(V, bool), 2: np.isin(slot_part, of.used_parts),
                3: np.isin(slot_part, sorted(of.adjustable))}
-    for kind in range(4):
-        nc = int(ncells[kind])
-        start = h.share_table(kind, 0)
-        rec = h.share_table(kind, 1).reshape(-1, 12)
-        rows = h.share_table(kind, 2)
+    for table in range(8):
+        kind, fine = table % 4, table >= 4
+        nc = int(ncells[table])
+        start = h.share_table(table, 0)
+        rec = h.share_table(table, 1).reshape(-1, 12)
+        rows = h.share_table(table, 2)
         assert len(start) == nc + 1 and start[0] == 0 and start[-1] == len(rec) - 1
         assert (rec[-1] == 0).all()  # sentinel
         seen = np.zeros(V, np.int32)
@@ -153,8 +155,8 @@ def check_share_tables(h, of, md, perm, V, plain=True):
         assert (seen == domains[kind].astype(np.int32)).all()
         assert row == (len(rows) // 12 if kind == 0 else len(rows))
         # balanced: the longest cell is within a few steps of the mean (the last one may be shorter)
-        assert max(costs) <= np.mean(costs) + 8, (kind, max(costs), np.mean(costs))
-        assert np.mean(costs) >= 60  # cells of ~75+ steps
+        assert max(costs) <= np.mean(costs) + 8, (table, max(costs), np.mean(costs))
+        assert np.mean(costs) >= (10 if fine else 60)  # cells of ~75+ steps (fine tables: 12+)
     # multiplier: one round of the chip where the batch allows it
     lib = _lib.load()
     if V > 6000 and plain:  # (the random-joint variant has a piece per vertex: 256 cells)

@@ -202,6 +202,56 @@ def test_edge_batches(model_root, golden, dev):
         m(pose_rotvecs=np.zeros((1, 72), np.float32))
 
 
+def test_stage_half(model_root, golden, dev, smplfit_env):
+    """Two instances per wave in the per-instance stages (J <= 32, batches from SMPLFIT_STAGE_HALF_B = 2048 up by
+    default): forced on at every batch size it must reproduce the reference's fixtures and agree with the
+    one-instance form on an odd batch (the last wave does instance B - 1 twice), in every caller of those stages."""
+    from smplfitter_amd.pt import BodyFitter
+
+    g = golden('smpl')
+    kind, md = util.load_md(model_root, 'smpl', g)
+    om64, _ = util.make_oracle(md, kind, np.float64)
+    m, f = get_model(model_root, 'smpl', g, dev)
+    fk = BodyFitter(m, enable_kid=True)
+    tv, tj = make_targets(m, 37, 11, dev)
+    w = torch.rand(37, m.num_vertices, device=dev) + 0.5
+    jw = torch.rand(37, m.num_joints, device=dev) + 0.5
+    keys = ['pose_rotvecs', 'shape_betas', 'trans']
+
+    def calls():
+        out = {}
+        out['fit'] = to_np(f.fit(tv, tj, num_iter=3, beta_regularizer=1.0, requested_keys=keys))
+        out['fit_nojoints'] = to_np(f.fit(tv, None, num_iter=2, beta_regularizer=1.0, final_adjust_rots=False, requested_keys=keys))
+        out['fit_weighted'] = to_np(f.fit(tv, tj, vertex_weights=w, joint_weights=jw, num_iter=2, requested_keys=keys))
+        out['fit_kid'] = to_np(fk.fit(tv, tj, num_iter=2, beta_regularizer=1.0, requested_keys=keys))
+        out['share_beta'] = to_np(f.fit(tv, tj, num_iter=2, share_beta=True, requested_keys=keys))
+        out['scale'] = to_np(f.fit(tv, tj, num_iter=2, scale_target=True, requested_keys=keys))
+        pose = torch.from_numpy(out['fit']['pose_rotvecs']).to(dev)
+        betas = torch.from_numpy(out['fit']['shape_betas']).to(dev)
+        out['known_pose'] = to_np(f.fit_with_known_pose(pose, tv, tj, beta_regularizer=1.0))
+        out['known_shape'] = to_np(f.fit_with_known_shape(betas, tv, tj, num_iter=2))
+        return out
+
+    ref = calls()
+    smplfit_env('SMPLFIT_STAGE_HALF_B', '1')
+    half = calls()
+    for name in ref:
+        for k in ref[name]:
+            assert np.abs(half[name][k] - ref[name][k]).max() < 2e-5, (name, k)
+    for c in util.fit_configs(g):
+        cfg = util.cfg_from_name(c)
+        o = to_np(f.fit(
+            t(g['target_vertices'], dev), t(g['target_joints'], dev) if cfg['joints'] else None,
+            vertex_weights=t(g['vertex_weights'], dev) if cfg['weights'] else None,
+            joint_weights=t(g['joint_weights'], dev) if (cfg['weights'] and cfg['joints']) else None,
+            num_iter=cfg['num_iter'], beta_regularizer=cfg['beta_regularizer'],
+            final_adjust_rots=cfg['final_adjust_rots'], requested_keys=keys))
+        r = {k: g[f'fit.{c}.{k}'] for k in ('pose_rotvecs', 'shape_betas', 'trans')}
+        assert util.vertex_l2(om64, o, r) < 1e-4, c
+        assert np.abs(o['shape_betas'] - r['shape_betas']).max() < 1e-4, c
+        assert np.abs(o['pose_rotvecs'] - r['pose_rotvecs']).max() < 3e-4, c
+
+
 @pytest.mark.parametrize('name,B', [('smpl', 4096), ('smplx', 4096), ('smpl1024', 16384), ('smpl_w6', 4096), ('smpl_rnd', 4096)])
 def test_full_size_properties(name, B, model_root, golden, dev, vertex_path):
     """BASELINE.json configs 2-4 at full size: round trip (the reference's own acceptance test,
@@ -225,10 +275,18 @@ def test_full_size_properties(name, B, model_root, golden, dev, vertex_path):
     r2 = f.fit(tv, tj, num_iter=3, beta_regularizer=1.0, requested_keys=['pose_rotvecs'])
     for k in ('pose_rotvecs', 'shape_betas', 'trans'):
         assert torch.equal(r[k], r2[k]), k
-    s = slice(B // 2 - 5, B // 2 + 6)
+    # a slice fitted on its own gives the same bits (900 instances: the coarse cell tables, as the full batch); a
+    # SMALL slice takes the fine tables (sf_tables.h: other partial sums, added in another order) and agrees to
+    # rounding — small batches among themselves are bit-identical again (test_edge_batches)
+    s = slice(B // 2 - 450, B // 2 + 450)
     r3 = f.fit(tv[s], tj[s], num_iter=3, beta_regularizer=1.0, requested_keys=['pose_rotvecs'])
     for k in ('pose_rotvecs', 'shape_betas', 'trans'):
         assert torch.equal(r[k][s], r3[k]), k
+    s = slice(B // 2 - 5, B // 2 + 6)
+    r4 = f.fit(tv[s], tj[s], num_iter=3, beta_regularizer=1.0, requested_keys=['pose_rotvecs'])
+    # (pose on the thin-finger SMPL-X fixture: ill-conditioned in the reference itself, see test_fit_goldens)
+    for k, tol in (('pose_rotvecs', 5e-3 if name == 'smplx' else 1e-4), ('shape_betas', 1e-4), ('trans', 1e-5)):
+        assert (r[k][s] - r4[k]).abs().max().item() < tol, k
     # orientations are proper rotations
     R = r['orientations']
     eye = torch.eye(3, device=dev)
