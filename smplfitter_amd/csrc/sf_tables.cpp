@@ -171,13 +171,13 @@ void build_share_tables(HostTables& t) {
   }
 }
 
-int pick_share_mult(const HostTables& t, int kind, int nblocks, int slots) {
+int pick_share_mult(const HostTables& t, int kind, int nblocks, int slots, int wg_waves) {
   // a wave's prologue (cell record, piece record, joints, first streams: dependent round trips) costs about a dozen steps
   constexpr long kPrologue = 12;
   const ShareTable& st = t.shares[kind];
   int best = 1;
   long best_cost = -1;
-  for (int m = 1; m <= 16 && st.ncells % (m * kBmWaves) == 0; m *= 2) {
+  for (int m = 1; m <= 16 && st.ncells % (m * wg_waves) == 0; m *= 2) {
     const long waves = (long)nblocks * (st.ncells / m), rounds = (waves + slots - 1) / slots;
     const long c = rounds * ((long)m * st.max_cost + kPrologue);
     if (best_cost < 0 || c < best_cost) {

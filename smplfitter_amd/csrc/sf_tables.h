@@ -228,7 +228,7 @@ void build_tiled_gemm_images(HostTables& t);
 std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsupported);
 // Cells per share (1, 2, 4, ...) of a batch-major vertex pass of `kind` over `nblocks` instance blocks on `slots`
 // resident waves: the multiplier with the smallest rounds x (share length + prologue) estimate.
-int pick_share_mult(const HostTables& t, int kind, int nblocks, int slots);
+int pick_share_mult(const HostTables& t, int kind, int nblocks, int slots, int wg_waves = kBmWaves);
 void build_share_tables(HostTables& t);
 
 }  // namespace sf

@@ -231,6 +231,8 @@ struct Workspace {
   float* psumP;    // (rows, 16, Mp) part sums per row of the LBS share table
   float* resP;     // ([share][16] + [segment row][3 kGQ], Mp) residual-pass sums (k_residual_bm); scratch of the layout pass
   float* gramP;    // (workgroups of k_pair_gram_bm, NG, Mp) pair-Gram partial sums
+  float* wT;       // (Mp/64, Vp, 64) vertex weights at the sorted slots (padding slots: 0), k_layout_weights
+  float* accP;     // (cells, NE+1, Mp) cell records of the weighted accumulate (k_accum_w_bm)
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -298,6 +300,12 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w, bool fwd_
     const size_t nslab = ((size_t)t.V + SMPLFIT_SLAB - 1) / SMPLFIT_SLAB;
     ws.psumP = (float*)take(lbs_rows * 16 * Mp * 4);
     ws.resP = (float*)take(std::max(res_rows, 3 * nslab) * Mp * 4);
+    // weighted fits on the batch-major path: the weight stream and the cell records of k_accum_w_bm
+    size_t acc_cells = 0;
+    for (size_t k = sf::kShareResidual; k < t.shares.size(); k += sf::kShareKinds)
+      if ((int)k < sf::kShareFine || B <= sf::kFineMaxBatch) acc_cells = std::max(acc_cells, (size_t)t.shares[k].ncells);
+    ws.wT = (float*)take(t.shares.empty() ? 0 : Mp * Vp * 4);
+    ws.accP = (float*)take(acc_cells * NE1 * Mp * 4);
   }
   {  // k_pair_gram_bm: one upper triangle per workgroup of 8 units (2 per joint + chunks of 4 pairs), NG <= NE
     const size_t units = 2 * J + (t.pair_c3.size() + 3) / 4;
@@ -355,6 +363,7 @@ struct Tuning {
   bool lbs_all_last = false;  // SMPLFIT_LBS_LAST=all: the last part sums of a fit over every used part (A/B of the adjustable-parts pass)
   int stage_half_b = 2048; // SMPLFIT_STAGE_HALF_B: smallest batch whose per-instance stages run two instances per wave (J <= 32)
   int fine_b = sf::kFineMaxBatch;  // SMPLFIT_FINE_B: largest batch that takes the fine cell tables (0: none; at most sf::kFineMaxBatch)
+  bool bm_weighted = true; // SMPLFIT_BM_WEIGHTED=0: fits with vertex weights on the wave-per-instance kernels (A/B)
   int bm_slots = 4096;     // SMPLFIT_BM_SLOTS: resident waves a batch-major vertex pass is dealt for (share-count choice)
   int bm_lds_kb = 0;       // SMPLFIT_BM_LDS_KB: LDS request of the two batch-major vertex passes padded to this (54: three
                            // workgroups per CU instead of four, which leaves registers / LDS for another chunk's small kernels)
@@ -375,6 +384,7 @@ Tuning read_tuning() {
   if (const char* e = env("SMPLFIT_GEMM_NCHUNK")) t.gemm_nchunk = std::max(1, atoi(e));
   if (const char* e = env("SMPLFIT_GEMM_LDS_KB")) t.gemm_lds_kb = atoi(e);
   if (const char* e = env("SMPLFIT_LBS_LAST")) t.lbs_all_last = e[0] == 'a';
+  if (const char* e = env("SMPLFIT_BM_WEIGHTED")) t.bm_weighted = e[0] != '0';
   if (const char* e = env("SMPLFIT_FINE_B")) t.fine_b = std::min(std::max(atoi(e), 0), sf::kFineMaxBatch);
   if (const char* e = env("SMPLFIT_STAGE_HALF_B")) t.stage_half_b = std::max(atoi(e), 1);
   if (const char* e = env("SMPLFIT_BM_SLOTS")) t.bm_slots = std::min(std::max(atoi(e), 256), 16384);
@@ -443,23 +453,28 @@ void launch_psum_combine(const DevModel& d, const ShareView& sv, const Workspace
 }
 
 // part sums of the centred targets against the template + their combine (the first rotation estimate)
-void launch_template_partsum_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStream_t st) {
+void launch_template_partsum_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStream_t st, bool weighted = false) {
   const DevModel& d = h->d;
   const int Mp = (int)align_up((size_t)B, 128);
   const ShareView sv = share_view(h, sf::kShareLbsUsed, B);
-  hipLaunchKernelGGL(k_template_partsum_bm, share_grid(sv, Mp), dim3(64 * kBW), 0, st, d, sv, ws, B, Mp);
+  if (weighted) hipLaunchKernelGGL(k_template_partsum_bm<true>, share_grid(sv, Mp), dim3(64 * kBW), 0, st, d, sv, ws, B, Mp);
+  else hipLaunchKernelGGL(k_template_partsum_bm<false>, share_grid(sv, Mp), dim3(64 * kBW), 0, st, d, sv, ws, B, Mp);
   launch_psum_combine(d, sv, ws, B, Mp, st);
 }
 
 // One-pass target layout of the batch-major path (k_layout_targets, k_mean_finish, k_template_partsum_bm):
 // ws.tT, ws.mean, ws.tjc and the template part sums ws.psum.  ws.resP serves as the slab-sum scratch.
-void launch_layout_bm(const smplfit_handle* h, const float* tv, const float* tj, const Workspace& ws, int B, hipStream_t st) {
+void launch_layout_bm(const smplfit_handle* h, const float* tv, const float* tj, const Workspace& ws, int B, hipStream_t st,
+                      const float* vw = nullptr) {
   const DevModel& d = h->d;
+  if (vw)  // vertex weights: their stream first (the template part sums below read it)
+    hipLaunchKernelGGL(k_layout_weights, dim3((d.V + 63) / 64 + 1, (int)align_up((size_t)B, 128) / 64), dim3(256), 0, st, d, vw,
+                       ws.wT, B);
   const int Mp = (int)align_up((size_t)B, 128), nslab = (d.V + kSlabV - 1) / kSlabV;
   hipLaunchKernelGGL(k_layout_targets, dim3(nslab, Mp / 64), dim3(256), (size_t)64 * kSlabRow * 4, st, d, tv, ws.tT,
                      ws.resP, B, Mp);
   hipLaunchKernelGGL(k_mean_finish, dim3(Mp / 64), dim3(64 * kMeanWaves), 0, st, d, tj, ws.resP, ws, B, Mp, nslab);
-  launch_template_partsum_bm(h, ws, B, st);
+  launch_template_partsum_bm(h, ws, B, st, vw != nullptr);
 }
 
 // K3' + K3g + K3c of the batch-major path for 10 betas (S = 10) and 10 betas + the kid unknown (S = 11)
@@ -487,21 +502,39 @@ void launch_residual_bm(const smplfit_handle* h, const Workspace& ws, int B, hip
   else launch_residual_bm_s<10>(h, ws, B, st, which);
 }
 
+// the weighted vertex block of the normal equations on the batch-major path (S = 10): cell records + their combine
+void launch_accum_w_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStream_t st) {
+  const DevModel& d = h->d;
+  const int Mp = (int)align_up((size_t)B, 128);
+  ShareView sv = share_view(h, sf::kShareResidual, B);
+  // one wave per workgroup, one workgroup per SIMD (its LDS): the multiplier for rounds of 1024 single waves
+  sv.mult = sf::pick_share_mult(h->t, share_index(sf::kShareResidual, B), Mp / 64, 1024, 1);
+  hipLaunchKernelGGL((k_accum_w_bm<10>), dim3(Mp / 64, sv.ncells / sv.mult), dim3(64), accum_w_lds<10>(), st, d, sv, ws, B, Mp);
+  constexpr int NE1 = sf::ne_size(10) + 1;
+  if (sv.fine) hipLaunchKernelGGL((k_accum_combine<10, 16>), dim3(Mp / 64, NE1), dim3(64 * 16), 0, st, sv, ws, B, Mp);
+  else hipLaunchKernelGGL((k_accum_combine<10, 4>), dim3(Mp / 64, NE1), dim3(64 * 4), 0, st, sv, ws, B, Mp);
+}
+
 // write_v (joints-omitted fits): every slot, the vertices at the solution written over ws.vpT, then the reference
 // joints of the next rotation pass regressed from them into ws.rjreg.  adj_only (the last pass of a fit with target
 // joints): the part sums feed the dependent refinement alone, which reads them at the adjustable parts
 // (bodyfitter.py:1505-1517) — only those parts' slots are visited, the other rows of ws.psum become zero.
 template <int S, int KW>
 void launch_lbs_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStream_t st, bool write_v = false,
-                   bool adj_only = false) {
+                   bool adj_only = false, bool weighted = false) {
   const DevModel& d = h->d;
   const int Mp = (int)align_up((size_t)B, 128);
   const size_t lds = (size_t)tune().bm_lds_kb * 1024;
   const ShareView sv = share_view(h, write_v ? sf::kShareLbsAll : adj_only ? sf::kShareLbsAdj : sf::kShareLbsUsed, B);
   if constexpr (KW == 4 && S <= 12) {  // what bm_applies admits (10 betas with or without the kid unknown)
     if (write_v) {
-      hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4, true>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp);
+      if (weighted)
+        hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4, true, false, true>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp);
+      else
+        hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4, true>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp);
       hipLaunchKernelGGL(k_regress_joints_bm<false>, dim3(Mp / 64, d.J), dim3(64), 0, st, d, ws.vpT, nullptr, ws.rjreg, B);
+    } else if (weighted) {
+      hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4, false, false, true>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp);
     } else {
       hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp);
     }
@@ -850,7 +883,11 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   // joints (bodyfitter.py:1018-1028)
   const bool eff_v = joints ? (vw && jw) : (vw != nullptr);
   const bool eff_j = joints && vw && jw;
-  const bool bm = bm_applies(h) && !vw && !o.rotations_only && !o.scale_mode;
+  // vertex weights on the batch-major path: the weight stream, weighted part sums, and — when the weights enter the
+  // shape solve — the weighted accumulate (built for 10 unknowns; with the kid unknown such a fit stays on the
+  // wave-per-instance kernels)
+  const bool bm_base = bm_applies(h) && !o.rotations_only && !o.scale_mode;
+  const bool bm = bm_base && (!vw || (tune().bm_weighted && (!eff_v || d.S == 10)));
   if (o.source && !bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "fused conversion: the batch-major path does not apply");
   // a warm-started fit evaluates its first part sums against the posed model with the wave-per-instance
   // kernel, which reads the per-instance sorted copy ws.tvs: that copy is produced as well then
@@ -859,7 +896,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   } else if (bm && o.source) {
     if (int rc = launch_convert_source(*o.source, d, ws, B, st)) return rc;
   } else if (bm) {
-    launch_layout_bm(h, tv, tj, ws, B, st);
+    launch_layout_bm(h, tv, tj, ws, B, st, vw);
   }
   const float* tj_rot = ws.tjc;
   if (!joints) {  // regressed target joints from the centred vertices (bodyfitter.py:1342-1344)
@@ -935,7 +972,8 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
       // one float each — instead of this 8 us launch: 2.54 -> 2.50 M fits/s, SMPL-X 1.31 -> 1.24: the scattered
       // stores cost the latency-bound stage more than the transpose.)
       launch_jd_transpose(d, ws, B, st);
-      launch_residual_bm(h, ws, B, st);
+      if (eff_v) launch_accum_w_bm(h, ws, B, st);
+      else launch_residual_bm(h, ws, B, st);
     } else {
       launch_gemm(d, ws, B, st);
 #define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, B, eff_v, st)
@@ -944,7 +982,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     }
     // K4 stays its own launch: fused into the prologue of the LBS kernel (template flag SOLVE) its
     // ~40 serial barriers stall all four waves of the workgroup and the kernel ran 230 us longer
-    const int pair_in = (bm || (!eff_v && use_pair_form())) ? 1 : 0;
+    const int pair_in = (!eff_v && (bm || use_pair_form())) ? 1 : 0;
     const bool scaled_now = o.scale_mode && it + 1 == o.num_iter;  // only the last solve (:434-455)
     if (pb)
       if (int rc = enqueue_solve(d, ws, B, o, joints, eff_v, eff_j, jw, pair_in, use_ref, scaled_now, st)) return rc;
@@ -952,7 +990,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     if (last && !o.final_adjust) break;  // nothing consumes the re-evaluated mesh
     if (!pb) {
     } else if (bm) {
-#define SF_CALL_LBS(S_, KW_) launch_lbs_bm<S_, KW_>(h, ws, B, st, !joints, last && joints && !tune().lbs_all_last)
+#define SF_CALL_LBS(S_, KW_) launch_lbs_bm<S_, KW_>(h, ws, B, st, !joints, last && joints && !tune().lbs_all_last, vweighted)
       SF_DISPATCH_SKW(d, SF_CALL_LBS);
 #undef SF_CALL_LBS
     } else if (joints) {
@@ -2052,7 +2090,7 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
         if (!bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "template part sums: batch-major path not active");
         {
           const ShareView sv = share_view(h, sf::kShareLbsUsed, batch);
-          hipLaunchKernelGGL(k_template_partsum_bm, share_grid(sv, Mp), dim3(64 * kBW), 0, st, d, sv, ws, batch, Mp);
+          hipLaunchKernelGGL(k_template_partsum_bm<false>, share_grid(sv, Mp), dim3(64 * kBW), 0, st, d, sv, ws, batch, Mp);
         }
         return 0;
       case SMPLFIT_KERNEL_SHAPE_ACCUM: {
