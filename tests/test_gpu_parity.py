@@ -294,6 +294,50 @@ def test_full_size_properties(name, B, model_root, golden, dev, vertex_path):
     assert (torch.linalg.det(R) - 1).abs().max().item() < 1e-5
 
 
+def test_weighted_batch_major(model_root, golden, dev, smplfit_env):
+    """Vertex weights on the batch-major path (weight stream, weighted part sums, k_accum_w_bm) at full size: against
+    the fp64 oracle on sampled rows, against the wave-per-instance kernels (SMPLFIT_BM_WEIGHTED=0), run-to-run
+    determinism and slice independence; the three ways weights enter a fit (bodyfitter.py:1018-1028): vertex + joint
+    weights, vertex weights with the joints omitted, vertex weights alone beside given joints (part sums only)."""
+    g = golden('smpl')
+    kind, md = util.load_md(model_root, 'smpl', g)
+    om64, of64 = util.make_oracle(md, kind, np.float64)
+    m, f = get_model(model_root, 'smpl', g, dev)
+    B = 4096
+    tv, tj = make_targets(m, B, 7, dev, noise=0.003)
+    gen = torch.Generator(device='cpu').manual_seed(3)
+    vw = (torch.rand(B, m.num_vertices, generator=gen) * 1.5 + 0.1).to(dev)
+    jw = (torch.rand(B, m.num_joints, generator=gen) * 1.5 + 0.1).to(dev)
+    keys = ['pose_rotvecs', 'shape_betas', 'trans']
+    cases = {'vw_jw': dict(target_joints=tj, vertex_weights=vw, joint_weights=jw),
+             'vw_nojoints': dict(target_joints=None, vertex_weights=vw),
+             'vw_only': dict(target_joints=tj, vertex_weights=vw)}
+    rows = np.array([0, 1, 63, 64, 2047, 2048, 4095])
+    for name, kw in cases.items():
+        r = f.fit(tv, num_iter=3, beta_regularizer=1.0, requested_keys=keys, **kw)
+        assert all(torch.isfinite(r[k]).all() for k in keys), name
+        r2 = f.fit(tv, num_iter=3, beta_regularizer=1.0, requested_keys=keys, **kw)
+        for k in keys:
+            assert torch.equal(r[k], r2[k]), (name, k)
+        s = slice(B // 2 - 450, B // 2 + 450)
+        kws = {k: (v[s] if v is not None else None) for k, v in kw.items()}
+        r3 = f.fit(tv[s], num_iter=3, beta_regularizer=1.0, requested_keys=keys, **kws)
+        for k in keys:
+            assert torch.equal(r[k][s], r3[k]), (name, k)
+        ti = torch.from_numpy(rows).to(dev)
+        o = {k: r[k][ti].cpu().numpy() for k in keys}
+        kwn = {k: (v[ti].cpu().numpy() if v is not None else None) for k, v in kw.items()}
+        ref = of64.fit(tv[ti].cpu().numpy(), num_iter=3, beta_regularizer=1.0, **kwn)
+        assert util.vertex_l2(om64, o, ref) < 1e-4, name
+        assert np.abs(o['shape_betas'] - ref['shape_betas']).max() < 3e-4, name
+        assert np.abs(o['trans'] - ref['trans']).max() < 1e-5, name
+        smplfit_env('SMPLFIT_BM_WEIGHTED', '0')
+        rw = f.fit(tv, num_iter=3, beta_regularizer=1.0, requested_keys=keys, **kw)
+        smplfit_env('SMPLFIT_BM_WEIGHTED', None)
+        for k, tol in (('pose_rotvecs', 2e-4), ('shape_betas', 1e-4), ('trans', 1e-5)):
+            assert (r[k] - rw[k]).abs().max().item() < tol, (name, k)
+
+
 def test_pair_gram_form(model_root):
     """The alternative unit-weight shape solve (k_residual + k_pair_gram, SMPLFIT_SHAPE_FORM=pair:
     Gramian from joint-pair constants, residual moments scattered on the matrix pipe) must give the
