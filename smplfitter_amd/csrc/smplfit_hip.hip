@@ -221,6 +221,7 @@ struct Workspace {
   float* scale;    // (B) scale_corr of the known-shape fit
   float* regref;   // (B,S) ridge reference of the warm-started fit
   double* cen;     // (B, S*S+S) centred regularised systems of a share_beta fit; row B = their sum
+  double* cenP;    // (ceil(B/64), S*S+S) partial sums of the rows above (k_share_partial)
   float* vextra;   // (B,32) extra vertex sums of the scaled solve (scale_extras_vertex)
   float* beta_out; // (B,S) undivided shape of the scaled solve (ws.beta holds the evaluated one)
   float* tjs;      // (B,J,3) target joints times the scale (scale_target refinement)
@@ -281,6 +282,7 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w, bool fwd_
   ws.scale = (float*)take((size_t)B * 4);
   ws.regref = (float*)take((size_t)B * S * 4, true);
   ws.cen = (double*)take(((size_t)B + 1) * (S * S + S) * 8);
+  ws.cenP = (double*)take(((size_t)B + 63) / 64 * (S * S + S) * 8);
   ws.vextra = (float*)take((size_t)B * 32 * 4);
   ws.beta_out = (float*)take((size_t)B * S * 4);
   ws.tjs = (float*)take((size_t)B * J * 3 * 4);
@@ -844,6 +846,7 @@ int enqueue_solve(const DevModel& d, const Workspace& ws, int B, const FitOption
       sa.share = 1;
       sa.B = B;
       hipLaunchKernelGGL(k_shape_solve_scaled, dim3(B), dim3(64), lds, st, d, ws, sa);
+      hipLaunchKernelGGL(k_share_partial, dim3((B + 63) / 64), dim3(512), 0, st, ws, B, NC);
       hipLaunchKernelGGL(k_share_reduce, dim3(1), dim3(512), 0, st, ws, B, NC);
       if (o.share_allreduce && o.share_allreduce(o.share_user, ws.cen + (size_t)B * NC, NC, (void*)st) != 0)
         return fail(SMPLFIT_ERR_HIP, "the share_allreduce callback failed");
@@ -853,6 +856,7 @@ int enqueue_solve(const DevModel& d, const Workspace& ws, int B, const FitOption
   } else if (o.share_beta) {  // assemble per instance, sum over the batch, solve the sum + own translation
     const int NC = d.S * d.S + d.S;
     launch_shape_solve(d, ws, B, st, o.beta_reg, o.beta_reg2, o.kid_reg, pair_in, 0, 1);
+    hipLaunchKernelGGL(k_share_partial, dim3((B + 63) / 64), dim3(512), 0, st, ws, B, NC);
     hipLaunchKernelGGL(k_share_reduce, dim3(1), dim3(512), 0, st, ws, B, NC);
     if (o.share_allreduce && o.share_allreduce(o.share_user, ws.cen + (size_t)B * NC, NC, (void*)st) != 0)
       return fail(SMPLFIT_ERR_HIP, "the share_allreduce callback failed");
