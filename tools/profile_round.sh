@@ -13,7 +13,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 SMPLFIT_CHUNKS=1 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $OUT/pmc_MFMA -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs > $OUT/pmc_MFMA.log 2>&1
 cd $R
-python bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2>/dev/null
 python tools/profile_collect.py $OUT $TAG
+# the default line LAST, with this build's traffic figures in place (bench.py reads profiles/pmc_traffic.json)
+cp $OUT/out/pmc_traffic.json profiles/pmc_traffic.json
+python bench.py --steps 20 --warmup 5 > $OUT/out/${TAG}_bench_default.json 2>/dev/null
 # keep the merge-back small: the raw traces stay on the box
 rm -rf $OUT/trace1 $OUT/trace2 $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_MFMA
