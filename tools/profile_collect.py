@@ -56,7 +56,7 @@ def stats_csv(rows, path, head, chunks, warm=3):
             f'{tot/1e3:.2f} ms ({tot/nfit:.1f} us per fit), >= 1 kernel in flight {100*b1/span:.1f} %, >= 2 kernels {100*b2/span:.1f} %')
 
 
-bench = json.load(open(f'{src}/bench_default.json'))
+bench = json.load(open(f'{src}/bench_chunks1.json'))  # build id / configuration (the default line is measured after this script)
 build = bench['build']
 head = f'rocprofv3 --kernel-trace of `python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs`, build "{build}", git HEAD see profiles/README.md'
 lines = []
