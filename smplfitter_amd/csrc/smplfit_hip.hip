@@ -365,6 +365,7 @@ struct Tuning {
   bool lbs_all_last = false;  // SMPLFIT_LBS_LAST=all: the last part sums of a fit over every used part (A/B of the adjustable-parts pass)
   int stage_half_b = 2048; // SMPLFIT_STAGE_HALF_B: smallest batch whose per-instance stages run two instances per wave (J <= 32)
   int fine_b = sf::kFineMaxBatch;  // SMPLFIT_FINE_B: largest batch that takes the fine cell tables (0: none; at most sf::kFineMaxBatch)
+  bool bm_known_shape = true;  // SMPLFIT_BM_KNOWN_SHAPE=0: fit_with_known_shape on the wave-per-instance kernels (A/B)
   bool bm_weighted = true; // SMPLFIT_BM_WEIGHTED=0: fits with vertex weights on the wave-per-instance kernels (A/B)
   int bm_slots = 4096;     // SMPLFIT_BM_SLOTS: resident waves a batch-major vertex pass is dealt for (share-count choice)
   int bm_lds_kb = 0;       // SMPLFIT_BM_LDS_KB: LDS request of the two batch-major vertex passes padded to this (54: three
@@ -386,6 +387,7 @@ Tuning read_tuning() {
   if (const char* e = env("SMPLFIT_GEMM_NCHUNK")) t.gemm_nchunk = std::max(1, atoi(e));
   if (const char* e = env("SMPLFIT_GEMM_LDS_KB")) t.gemm_lds_kb = atoi(e);
   if (const char* e = env("SMPLFIT_LBS_LAST")) t.lbs_all_last = e[0] == 'a';
+  if (const char* e = env("SMPLFIT_BM_KNOWN_SHAPE")) t.bm_known_shape = e[0] != '0';
   if (const char* e = env("SMPLFIT_BM_WEIGHTED")) t.bm_weighted = e[0] != '0';
   if (const char* e = env("SMPLFIT_FINE_B")) t.fine_b = std::min(std::max(atoi(e), 0), sf::kFineMaxBatch);
   if (const char* e = env("SMPLFIT_STAGE_HALF_B")) t.stage_half_b = std::max(atoi(e), 1);
@@ -1057,11 +1059,27 @@ int run_fit_known_shape(const smplfit_handle* h, const float* betas, int nb, con
     return fail(SMPLFIT_ERR_BAD_ARG,
                 "target_joints omitted but the model has no J_regressor_post_lbs over its vertices");
   const bool vweighted = vw != nullptr;
-  launch_center_sort(d, tv, tj, vw, ws, B, st);
+  // the batch-major vertex kernels (round 4): target (+ weight) streams, transposed GEMM, part sums with lane =
+  // instance (the LAST pass leaves the posed vertices in ws.vpT), alignment sums over the streams
+  const bool bm = bm_applies(h) && (!vw || tune().bm_weighted) && tune().bm_known_shape;
+  const int Mp = (int)align_up((size_t)B, 128);
   const float* tj_rot = ws.tjc;
-  if (!joints) {
-    hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(64), 0, st, d, ws.tvs, ws.tjreg);
-    tj_rot = ws.tjreg;
+  if (bm) {
+    const int nslab = (d.V + kSlabV - 1) / kSlabV;
+    if (vw) hipLaunchKernelGGL(k_layout_weights, dim3((d.V + 63) / 64 + 1, Mp / 64), dim3(256), 0, st, d, vw, ws.wT, B);
+    hipLaunchKernelGGL(k_layout_targets, dim3(nslab, Mp / 64), dim3(256), (size_t)64 * kSlabRow * 4, st, d, tv, ws.tT, ws.resP,
+                       B, Mp);
+    hipLaunchKernelGGL(k_mean_finish, dim3(Mp / 64), dim3(64 * kMeanWaves), 0, st, d, tj, ws.resP, ws, B, Mp, nslab);
+    if (!joints) {
+      hipLaunchKernelGGL(k_regress_joints_bm<true>, dim3(Mp / 64, d.J), dim3(64), 0, st, d, ws.tT, ws.mean, ws.tjreg, B);
+      tj_rot = ws.tjreg;
+    }
+  } else {
+    launch_center_sort(d, tv, tj, vw, ws, B, st);
+    if (!joints) {
+      hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(64), 0, st, d, ws.tvs, ws.tjreg);
+      tj_rot = ws.tjreg;
+    }
   }
   hipLaunchKernelGGL(k_fill_shape, dim3((B + 255) / 256), dim3(256), 0, st, ws, B, d.S, d.jt.n_kid, betas,
                      std::min(nb, d.S - d.jt.n_kid - d.jt.n_pad), kid);
@@ -1080,14 +1098,24 @@ int run_fit_known_shape(const smplfit_handle* h, const float* betas, int nb, con
   ja.Gprev = ws.G;
   for (int it = 0; it <= o.num_iter; ++it) {
     hipLaunchKernelGGL(k_forward_joint, dim3(B), dim3(64), joint_lds(d), st, d, fa, ws);
-    launch_gemm(d, ws, B, st);
-    // MODE 1: the posed mesh is kept (regressed joints, alignment sums) next to the part sums
+    if (bm) {
+      if (int rc = launch_gemm(d, ws, B, st, true)) return rc;
+      launch_jd_transpose(d, ws, B, st);
+      // the posed mesh is kept (in place, ws.vpT) where it is read: regressed joints, and the alignment sums behind the
+      // last pass
+#define SF_CALL_LBS(S_, KW_) launch_lbs_bm<S_, KW_>(h, ws, B, st, !joints || it == o.num_iter, false, vweighted)
+      SF_DISPATCH_SKW(d, SF_CALL_LBS);
+#undef SF_CALL_LBS
+    } else {
+      launch_gemm(d, ws, B, st);
+      // MODE 1: the posed mesh is kept (regressed joints, alignment sums) next to the part sums
 #define SF_CALL_LBS(S_, KW_) \
   launch_lbs<S_, KW_, 1, false>(d, ws, B, vweighted, d.S, ws.beta, ws.trans, nullptr, 0.f, 0.f, st)
-    SF_DISPATCH_SKW(d, SF_CALL_LBS);
+      SF_DISPATCH_SKW(d, SF_CALL_LBS);
 #undef SF_CALL_LBS
-    if (!joints)
-      hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(64), 0, st, d, ws.rverts, ws.rjreg);
+      if (!joints)
+        hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(64), 0, st, d, ws.rverts, ws.rjreg);
+    }
     if (it == o.num_iter) break;
     ja.rj = joints ? ws.rjoints : ws.rjreg;
     launch_joint_stage(d, ja, ws, B, st);
@@ -1102,7 +1130,28 @@ int run_fit_known_shape(const smplfit_handle* h, const float* betas, int nb, con
   sa.with_scale = o.scale_fit;
   sa.regressed = joints ? 0 : 1;
   sa.scale_out = o.scale_fit ? scale_out : nullptr;
-  hipLaunchKernelGGL(k_scale_trans, dim3(B), dim3(256), 0, st, d, sa, ws);
+  if (bm) {
+    AlignArgs aa{};
+    aa.tj = sa.tj;
+    aa.jw = sa.jw;
+    aa.with_scale = o.scale_fit;
+    aa.regressed = sa.regressed;
+    aa.scale_out = sa.scale_out;
+    aa.nchunk = B <= sf::kFineMaxBatch ? 256 : 64;
+    const dim3 grid(Mp / 64, aa.nchunk);
+    if (sa.weighted_v) hipLaunchKernelGGL((k_align_partial_bm<1, true>), grid, dim3(64), 0, st, d, ws, B, Mp, aa.nchunk);
+    else hipLaunchKernelGGL((k_align_partial_bm<1, false>), grid, dim3(64), 0, st, d, ws, B, Mp, aa.nchunk);
+    aa.mode = 1;
+    hipLaunchKernelGGL(k_align_finish, dim3(B), dim3(64), 0, st, d, aa, ws, B, Mp);
+    if (o.scale_fit) {
+      if (sa.weighted_v) hipLaunchKernelGGL((k_align_partial_bm<2, true>), grid, dim3(64), 0, st, d, ws, B, Mp, aa.nchunk);
+      else hipLaunchKernelGGL((k_align_partial_bm<2, false>), grid, dim3(64), 0, st, d, ws, B, Mp, aa.nchunk);
+      aa.mode = 2;
+      hipLaunchKernelGGL(k_align_finish, dim3(B), dim3(64), 0, st, d, aa, ws, B, Mp);
+    }
+  } else {
+    hipLaunchKernelGGL(k_scale_trans, dim3(B), dim3(256), 0, st, d, sa, ws);
+  }
   RefineArgs ra{};
   ra.tj = tj_rot;
   ra.rj_term = joints ? ws.rjoints : ws.rjreg;

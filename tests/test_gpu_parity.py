@@ -550,10 +550,13 @@ def test_convert_fused_matches_unfused(model_root, golden, dev, data_root_fat, m
         assert np.abs(res['fused']['trans'] - res['unfused']['trans']).max() < 2e-5
 
 
+@pytest.mark.parametrize('path', ['batch-major', 'wave-per-instance'])
 @pytest.mark.parametrize('name', ['smpl', 'smplx'])
-def test_known_shape_goldens(name, model_root, golden, dev):
+def test_known_shape_goldens(name, path, model_root, golden, dev, smplfit_env):
     """BodyFitter.fit_with_known_shape (smplfit_fit_known_shape_f32) against the reference's fixture:
-    num_iter 1..3, joints given / omitted, weights, scale_fit, kid_factor, warm start, no final adjust."""
+    num_iter 1..3, joints given / omitted, weights, scale_fit, kid_factor, warm start, no final adjust — on the
+    batch-major vertex kernels (the default) and on the wave-per-instance ones (SMPLFIT_BM_KNOWN_SHAPE=0)."""
+    smplfit_env('SMPLFIT_BM_KNOWN_SHAPE', '1' if path == 'batch-major' else '0')
     g, ge = golden(name), golden(f'ext_{name}')
     kind, md = util.load_md(model_root, name, g)
     om, _ = util.make_oracle(md, kind, np.float64)
@@ -602,6 +605,35 @@ def test_known_shape_vs_oracle_and_roundtrip(model_root, golden, dev):
             assert np.abs(r['scale_corr'] - o['scale_corr']).max() < 1e-5
         else:  # 3 mm of noise: the fitted mesh is within a few mm of the clean one
             assert np.linalg.norm(va - fw['vertices'], axis=-1).mean() < 5e-3
+
+
+def test_known_shape_full_size(model_root, golden, dev, smplfit_env):
+    """fit_with_known_shape at B = 4096 (the coarse cell tables; the fixtures run on the fine ones): the batch-major
+    kernels against the wave-per-instance ones, with weights / scale_fit / joints omitted, and run-to-run."""
+    g = golden('smpl')
+    m, f = get_model(model_root, 'smpl', g, dev)
+    B = 4096
+    rs = np.random.RandomState(9)
+    betas = t((rs.randn(B, 10) * 0.7).astype(np.float32), dev)
+    fw = m(t((rs.randn(B, 72) * 0.15).astype(np.float32), dev), betas, t(rs.randn(B, 3).astype(np.float32), dev))
+    gen = torch.Generator(device='cpu').manual_seed(4)
+    tv = fw['vertices'] + (torch.randn(fw['vertices'].shape, generator=gen) * 0.003).to(dev)
+    tj = fw['joints']
+    vw = (torch.rand(B, m.num_vertices, generator=gen) + 0.2).to(dev)
+    jw = (torch.rand(B, m.num_joints, generator=gen) + 0.2).to(dev)
+    cases = {'plain': dict(target_joints=tj, num_iter=2),
+             'weights_scale': dict(target_joints=tj, vertex_weights=vw, joint_weights=jw, num_iter=2, scale_fit=True),
+             'no_joints': dict(target_joints=None, vertex_weights=vw, num_iter=1)}
+    for name, kw in cases.items():
+        a = f.fit_with_known_shape(betas, tv, **kw)
+        a2 = f.fit_with_known_shape(betas, tv, **kw)
+        smplfit_env('SMPLFIT_BM_KNOWN_SHAPE', '0')
+        w = f.fit_with_known_shape(betas, tv, **kw)
+        smplfit_env('SMPLFIT_BM_KNOWN_SHAPE', None)
+        for k in a:
+            assert torch.equal(a[k], a2[k]), (name, k)
+            tol = 1e-5 if k in ('trans', 'scale_corr') else 2e-4
+            assert (a[k] - w[k]).abs().max().item() < tol, (name, k)
 
 
 @pytest.mark.parametrize('name', ['smpl', 'smplx'])
