@@ -513,7 +513,8 @@ void launch_accum_w_bm(const smplfit_handle* h, const Workspace& ws, int B, hipS
   ShareView sv = share_view(h, sf::kShareResidual, B);
   // one wave per workgroup, one workgroup per SIMD (its LDS): the multiplier for rounds of 1024 single waves
   sv.mult = sf::pick_share_mult(h->t, share_index(sf::kShareResidual, B), Mp / 64, 1024, 1);
-  hipLaunchKernelGGL((k_accum_w_bm<10>), dim3(Mp / 64, sv.ncells / sv.mult), dim3(64), accum_w_lds<10>(), st, d, sv, ws, B, Mp);
+  hipLaunchKernelGGL((k_accum_w_bm<10, kAccWaves>), dim3(Mp / 64, sv.ncells / sv.mult), dim3(64 * kAccWaves), accum_w_lds<10>(), st,
+                     d, sv, ws, B, Mp);
   constexpr int NE1 = sf::ne_size(10) + 1;
   if (sv.fine) hipLaunchKernelGGL((k_accum_combine<10, 16>), dim3(Mp / 64, NE1), dim3(64 * 16), 0, st, sv, ws, B, Mp);
   else hipLaunchKernelGGL((k_accum_combine<10, 4>), dim3(Mp / 64, NE1), dim3(64 * 4), 0, st, sv, ws, B, Mp);
