@@ -237,6 +237,7 @@ struct Workspace {
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+constexpr int kAccExtrasHost = 16;  // (= kAccExtras of kernels_bm.inc: the extras of the scaled solve behind a cell record)
 
 #ifndef SMPLFIT_SLAB
 #define SMPLFIT_SLAB 32  // original vertices per workgroup of k_layout_targets (kSlabV)
@@ -307,7 +308,7 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w, bool fwd_
     for (size_t k = sf::kShareResidual; k < t.shares.size(); k += sf::kShareKinds)
       if ((int)k < sf::kShareFine || B <= sf::kFineMaxBatch) acc_cells = std::max(acc_cells, (size_t)t.shares[k].ncells);
     ws.wT = (float*)take(t.shares.empty() ? 0 : Mp * Vp * 4);
-    ws.accP = (float*)take(acc_cells * NE1 * Mp * 4);
+    ws.accP = (float*)take(acc_cells * (NE1 + kAccExtrasHost) * Mp * 4);
   }
   {  // k_pair_gram_bm: one upper triangle per workgroup of 8 units (2 per joint + chunks of 4 pairs), NG <= NE
     const size_t units = 2 * J + (t.pair_c3.size() + 3) / 4;
@@ -365,6 +366,7 @@ struct Tuning {
   bool lbs_all_last = false;  // SMPLFIT_LBS_LAST=all: the last part sums of a fit over every used part (A/B of the adjustable-parts pass)
   int stage_half_b = 2048; // SMPLFIT_STAGE_HALF_B: smallest batch whose per-instance stages run two instances per wave (J <= 32)
   int fine_b = sf::kFineMaxBatch;  // SMPLFIT_FINE_B: largest batch that takes the fine cell tables (0: none; at most sf::kFineMaxBatch)
+  bool bm_scale = true;    // SMPLFIT_BM_SCALE=0: fit(scale_target / scale_fit) on the wave-per-instance kernels (A/B)
   bool bm_known_shape = true;  // SMPLFIT_BM_KNOWN_SHAPE=0: fit_with_known_shape on the wave-per-instance kernels (A/B)
   bool bm_weighted = true; // SMPLFIT_BM_WEIGHTED=0: fits with vertex weights on the wave-per-instance kernels (A/B)
   int bm_slots = 4096;     // SMPLFIT_BM_SLOTS: resident waves a batch-major vertex pass is dealt for (share-count choice)
@@ -387,6 +389,7 @@ Tuning read_tuning() {
   if (const char* e = env("SMPLFIT_GEMM_NCHUNK")) t.gemm_nchunk = std::max(1, atoi(e));
   if (const char* e = env("SMPLFIT_GEMM_LDS_KB")) t.gemm_lds_kb = atoi(e);
   if (const char* e = env("SMPLFIT_LBS_LAST")) t.lbs_all_last = e[0] == 'a';
+  if (const char* e = env("SMPLFIT_BM_SCALE")) t.bm_scale = e[0] != '0';
   if (const char* e = env("SMPLFIT_BM_KNOWN_SHAPE")) t.bm_known_shape = e[0] != '0';
   if (const char* e = env("SMPLFIT_BM_WEIGHTED")) t.bm_weighted = e[0] != '0';
   if (const char* e = env("SMPLFIT_FINE_B")) t.fine_b = std::min(std::max(atoi(e), 0), sf::kFineMaxBatch);
@@ -506,18 +509,29 @@ void launch_residual_bm(const smplfit_handle* h, const Workspace& ws, int B, hip
   else launch_residual_bm_s<10>(h, ws, B, st, which);
 }
 
-// the weighted vertex block of the normal equations on the batch-major path (S = 10): cell records + their combine
-void launch_accum_w_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStream_t st) {
+// the vertex block of the normal equations accumulated per vertex on the batch-major path (S = 10): cell records +
+// their combine.  weighted: the vertex weights enter (else unit weights); extras: also the sums of the scaled solve
+// (the last iteration of a scale_target / scale_fit fit)
+void launch_accum_w_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStream_t st, bool weighted = true,
+                       bool extras = false) {
+  static_assert(kAccExtrasHost == kAccExtras, "record layout");
   const DevModel& d = h->d;
   const int Mp = (int)align_up((size_t)B, 128);
   ShareView sv = share_view(h, sf::kShareResidual, B);
-  // one wave per workgroup, one workgroup per SIMD (its LDS): the multiplier for rounds of 1024 single waves
+  // four workgroups per CU (their LDS): the multiplier for rounds of 1024 workgroups
   sv.mult = sf::pick_share_mult(h->t, share_index(sf::kShareResidual, B), Mp / 64, 1024, 1);
-  hipLaunchKernelGGL((k_accum_w_bm<10, kAccWaves>), dim3(Mp / 64, sv.ncells / sv.mult), dim3(64 * kAccWaves), accum_w_lds<10>(), st,
-                     d, sv, ws, B, Mp);
+  const dim3 grid(Mp / 64, sv.ncells / sv.mult);
+  const size_t lds = accum_w_lds<10>();
+  if (!extras)
+    hipLaunchKernelGGL((k_accum_w_bm<10, kAccWaves>), grid, dim3(64 * kAccWaves), lds, st, d, sv, ws, B, Mp);
+  else if (weighted)
+    hipLaunchKernelGGL((k_accum_w_bm<10, 1, true, true>), grid, dim3(64), lds, st, d, sv, ws, B, Mp);
+  else
+    hipLaunchKernelGGL((k_accum_w_bm<10, 1, false, true>), grid, dim3(64), lds, st, d, sv, ws, B, Mp);
   constexpr int NE1 = sf::ne_size(10) + 1;
-  if (sv.fine) hipLaunchKernelGGL((k_accum_combine<10, 16>), dim3(Mp / 64, NE1), dim3(64 * 16), 0, st, sv, ws, B, Mp);
-  else hipLaunchKernelGGL((k_accum_combine<10, 4>), dim3(Mp / 64, NE1), dim3(64 * 4), 0, st, sv, ws, B, Mp);
+  const int nent = NE1 + (extras ? 10 + 6 : 0), unit = weighted ? 0 : 1;
+  if (sv.fine) hipLaunchKernelGGL((k_accum_combine<10, 16>), dim3(Mp / 64, nent), dim3(64 * 16), 0, st, d, sv, ws, B, Mp, unit);
+  else hipLaunchKernelGGL((k_accum_combine<10, 4>), dim3(Mp / 64, nent), dim3(64 * 4), 0, st, d, sv, ws, B, Mp, unit);
 }
 
 // write_v (joints-omitted fits): every slot, the vertices at the solution written over ws.vpT, then the reference
@@ -828,12 +842,14 @@ int launch_convert_source(const ConvertSource& src, const DevModel& d_out, const
 // batch [and the ranks], solve the sum).  The all-shared branch of the reference's lstsq_partial_share
 // drops the ridge reference (pt/lstsq.py:45-47): so does this.
 int enqueue_solve(const DevModel& d, const Workspace& ws, int B, const FitOptions& o, bool joints, bool eff_v,
-                  bool eff_j, const float* jw, int pair_in, int use_ref, bool scaled, hipStream_t st) {
+                  bool eff_j, const float* jw, int pair_in, int use_ref, bool scaled, hipStream_t st,
+                  bool extras_done = false) {
   if (scaled) {
+    // (extras_done: the batch-major accumulate of this iteration has left the extra sums in ws.vextra)
 #define SF_CALL_EXTRAS(S_, KW_)                                                                       \
   hipLaunchKernelGGL((k_scale_extras<S_, KW_>), dim3(B), dim3(64),                                    \
                      (size_t)d.J * sf::jd_stride(S_) * 4, st, d, ws, eff_v ? 1 : 0)
-    SF_DISPATCH_SKW(d, SF_CALL_EXTRAS);
+    if (!extras_done) SF_DISPATCH_SKW(d, SF_CALL_EXTRAS);
 #undef SF_CALL_EXTRAS
     ScaledSolveArgs sa{};
     sa.tj = joints ? ws.tjc : nullptr;
@@ -893,7 +909,9 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   // vertex weights on the batch-major path: the weight stream, weighted part sums, and — when the weights enter the
   // shape solve — the weighted accumulate (built for 10 unknowns; with the kid unknown such a fit stays on the
   // wave-per-instance kernels)
-  const bool bm_base = bm_applies(h) && !o.rotations_only && !o.scale_mode;
+  // scale_target / scale_fit: the LAST iteration's solve has one more unknown and needs extra vertex sums — that
+  // iteration runs the accumulate kernel (with or without weights) in its EXTRAS form
+  const bool bm_base = bm_applies(h) && !o.rotations_only && (!o.scale_mode || (tune().bm_scale && d.S == 10));
   const bool bm = bm_base && (!vw || (tune().bm_weighted && (!eff_v || d.S == 10)));
   if (o.source && !bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "fused conversion: the batch-major path does not apply");
   // a warm-started fit evaluates its first part sums against the posed model with the wave-per-instance
@@ -979,7 +997,8 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
       // one float each — instead of this 8 us launch: 2.54 -> 2.50 M fits/s, SMPL-X 1.31 -> 1.24: the scattered
       // stores cost the latency-bound stage more than the transpose.)
       launch_jd_transpose(d, ws, B, st);
-      if (eff_v) launch_accum_w_bm(h, ws, B, st);
+      if (o.scale_mode && it + 1 == o.num_iter) launch_accum_w_bm(h, ws, B, st, eff_v, true);
+      else if (eff_v) launch_accum_w_bm(h, ws, B, st);
       else launch_residual_bm(h, ws, B, st);
     } else {
       launch_gemm(d, ws, B, st);
@@ -989,10 +1008,13 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     }
     // K4 stays its own launch: fused into the prologue of the LBS kernel (template flag SOLVE) its
     // ~40 serial barriers stall all four waves of the workgroup and the kernel ran 230 us longer
-    const int pair_in = (!eff_v && (bm || use_pair_form())) ? 1 : 0;
     const bool scaled_now = o.scale_mode && it + 1 == o.num_iter;  // only the last solve (:434-455)
+    // (the accumulate kernel — weighted fits, and the scaled iteration on the batch-major path — leaves the complete
+    // record: the classic form of the solve; the residual pass the pair-Gram form)
+    const int pair_in = (!eff_v && !(bm && scaled_now) && (bm || use_pair_form())) ? 1 : 0;
     if (pb)
-      if (int rc = enqueue_solve(d, ws, B, o, joints, eff_v, eff_j, jw, pair_in, use_ref, scaled_now, st)) return rc;
+      if (int rc = enqueue_solve(d, ws, B, o, joints, eff_v, eff_j, jw, pair_in, use_ref, scaled_now, st, bm && scaled_now))
+        return rc;
     const bool last = it + 1 == o.num_iter;
     if (last && !o.final_adjust) break;  // nothing consumes the re-evaluated mesh
     if (!pb) {

@@ -866,12 +866,17 @@ def test_hipgraph_capture(B, model_root, golden, dev):
         assert torch.equal(out[k], eager[k]), k
 
 
+@pytest.mark.parametrize('path', ['batch-major', 'wave-per-instance'])
 @pytest.mark.parametrize('name', ['smpl', 'smplx'])
-def test_scale_goldens(name, model_root, golden, dev):
+def test_scale_goldens(name, path, model_root, golden, dev, smplfit_env):
     """fit(scale_target=True) / fit(scale_fit=True) (smplfit_fit_ex_f32, scale_mode) against the
     reference's fixture, and the reference's own acceptance test (tests/test_fitter_common.py:118-240):
-    a body scaled by 1.1 is recovered with scale_corr ~ 1/1.1 resp. 1.1."""
+    a body scaled by 1.1 is recovered with scale_corr ~ 1/1.1 resp. 1.1.  On the batch-major kernels (the last
+    iteration through the accumulate kernel with the extra sums of the scaled solve) and on the wave-per-instance ones
+    (SMPLFIT_BM_SCALE=0)."""
     from smplfitter_amd.pt import BodyFitter
+
+    smplfit_env('SMPLFIT_BM_SCALE', '1' if path == 'batch-major' else '0')
 
     g, ge = golden(name), golden(f'ext_{name}')
     kind, md = util.load_md(model_root, name, g)
