@@ -366,6 +366,7 @@ struct Tuning {
   bool lbs_all_last = false;  // SMPLFIT_LBS_LAST=all: the last part sums of a fit over every used part (A/B of the adjustable-parts pass)
   int stage_half_b = 2048; // SMPLFIT_STAGE_HALF_B: smallest batch whose per-instance stages run two instances per wave (J <= 32)
   int fine_b = sf::kFineMaxBatch;  // SMPLFIT_FINE_B: largest batch that takes the fine cell tables (0: none; at most sf::kFineMaxBatch)
+  bool bm_forward = true;  // SMPLFIT_BM_FORWARD=0: BodyModel.forward on the wave-per-instance LBS kernel (A/B)
   bool bm_scale = true;    // SMPLFIT_BM_SCALE=0: fit(scale_target / scale_fit) on the wave-per-instance kernels (A/B)
   bool bm_known_shape = true;  // SMPLFIT_BM_KNOWN_SHAPE=0: fit_with_known_shape on the wave-per-instance kernels (A/B)
   bool bm_weighted = true; // SMPLFIT_BM_WEIGHTED=0: fits with vertex weights on the wave-per-instance kernels (A/B)
@@ -389,6 +390,7 @@ Tuning read_tuning() {
   if (const char* e = env("SMPLFIT_GEMM_NCHUNK")) t.gemm_nchunk = std::max(1, atoi(e));
   if (const char* e = env("SMPLFIT_GEMM_LDS_KB")) t.gemm_lds_kb = atoi(e);
   if (const char* e = env("SMPLFIT_LBS_LAST")) t.lbs_all_last = e[0] == 'a';
+  if (const char* e = env("SMPLFIT_BM_FORWARD")) t.bm_forward = e[0] != '0';
   if (const char* e = env("SMPLFIT_BM_SCALE")) t.bm_scale = e[0] != '0';
   if (const char* e = env("SMPLFIT_BM_KNOWN_SHAPE")) t.bm_known_shape = e[0] != '0';
   if (const char* e = env("SMPLFIT_BM_WEIGHTED")) t.bm_weighted = e[0] != '0';
@@ -1862,7 +1864,22 @@ int smplfit_forward_ex_f32(const smplfit_handle* h, const smplfit_forward_args* 
   fa.joints = joints;
   fa.orient = args->orientations;
   hipLaunchKernelGGL(k_forward_joint, dim3(batch), dim3(64), joint_lds(d), st, d, fa, ws);
-  if (vertices) {
+  if (vertices && bm_applies(h) && tune().bm_forward) {
+    // the batch-major kernels (round 4; what the input side of a fused conversion runs): shape / translation rows, the
+    // transposed GEMM, the forward-only LBS pass over every slot (posed vertices in place in ws.vpT), and the inverse
+    // of the target layout into the caller's (B, V, 3)
+    const int Mp = (int)align_up((size_t)batch, 128);
+    hipLaunchKernelGGL(k_fill_shape, dim3((batch + 255) / 256), dim3(256), 0, st, ws, batch, d.S, d.jt.n_kid, shape_betas, fa.nb,
+                       kid_factor, trans);
+    if (int rc2 = launch_gemm(d, ws, batch, st, true)) return rc2;
+    launch_jd_transpose(d, ws, batch, st);
+    const ShareView sv = share_view(h, sf::kShareLbsAll, batch);
+    const dim3 grid = share_grid(sv, Mp);
+    if (d.S == 11) hipLaunchKernelGGL((k_lbs_partsum_bm<11, 4, true, true>), grid, dim3(64 * kBW), 0, st, d, sv, ws, batch, Mp);
+    else hipLaunchKernelGGL((k_lbs_partsum_bm<10, 4, true, true>), grid, dim3(64 * kBW), 0, st, d, sv, ws, batch, Mp);
+    hipLaunchKernelGGL(k_unlayout_vertices, dim3((d.V + kSlabV - 1) / kSlabV, Mp / 64), dim3(256), (size_t)64 * kSlabRow * 4, st, d,
+                       ws.vpT, vertices, batch);
+  } else if (vertices) {
     launch_gemm(d, ws, batch, st);
 #define SF_CALL_LBS(S_, KW_) \
   launch_lbs<S_, KW_, 2, false>(d, ws, batch, false, fa.nb, shape_betas, trans, vertices, 0.f, 0.f, st, kid_factor)

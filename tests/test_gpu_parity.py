@@ -47,8 +47,12 @@ def to_np(d):
     return {k: v.cpu().numpy() for k, v in d.items()}
 
 
+@pytest.mark.parametrize('path', ['batch-major', 'wave-per-instance'])
 @pytest.mark.parametrize('name', ['smpl', 'smplx', 'smpl1024'])
-def test_forward_goldens(name, model_root, golden, dev):
+def test_forward_goldens(name, path, model_root, golden, dev, smplfit_env):
+    """BodyModel.forward against the reference's fixture, on the batch-major kernels (transposed GEMM, forward-only LBS
+    pass, k_unlayout_vertices) and on the wave-per-instance LBS kernel (SMPLFIT_BM_FORWARD=0)."""
+    smplfit_env('SMPLFIT_BM_FORWARD', '1' if path == 'batch-major' else '0')
     g = golden(name)
     m, _ = get_model(model_root, name, g, dev)
     fw = to_np(m(t(g['pose'], dev), t(g['betas'], dev), t(g['trans'], dev)))
