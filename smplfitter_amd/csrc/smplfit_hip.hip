@@ -366,6 +366,7 @@ struct Tuning {
   bool lbs_all_last = false;  // SMPLFIT_LBS_LAST=all: the last part sums of a fit over every used part (A/B of the adjustable-parts pass)
   int stage_half_b = 2048; // SMPLFIT_STAGE_HALF_B: smallest batch whose per-instance stages run two instances per wave (J <= 32)
   int fine_b = sf::kFineMaxBatch;  // SMPLFIT_FINE_B: largest batch that takes the fine cell tables (0: none; at most sf::kFineMaxBatch)
+  bool bm_known_pose = true;  // SMPLFIT_BM_KNOWN_POSE=0: smplfit_shape_solve_ex_f32 on the wave-per-instance kernels (A/B)
   bool bm_forward = true;  // SMPLFIT_BM_FORWARD=0: BodyModel.forward on the wave-per-instance LBS kernel (A/B)
   bool bm_scale = true;    // SMPLFIT_BM_SCALE=0: fit(scale_target / scale_fit) on the wave-per-instance kernels (A/B)
   bool bm_known_shape = true;  // SMPLFIT_BM_KNOWN_SHAPE=0: fit_with_known_shape on the wave-per-instance kernels (A/B)
@@ -390,6 +391,7 @@ Tuning read_tuning() {
   if (const char* e = env("SMPLFIT_GEMM_NCHUNK")) t.gemm_nchunk = std::max(1, atoi(e));
   if (const char* e = env("SMPLFIT_GEMM_LDS_KB")) t.gemm_lds_kb = atoi(e);
   if (const char* e = env("SMPLFIT_LBS_LAST")) t.lbs_all_last = e[0] == 'a';
+  if (const char* e = env("SMPLFIT_BM_KNOWN_POSE")) t.bm_known_pose = e[0] != '0';
   if (const char* e = env("SMPLFIT_BM_FORWARD")) t.bm_forward = e[0] != '0';
   if (const char* e = env("SMPLFIT_BM_SCALE")) t.bm_scale = e[0] != '0';
   if (const char* e = env("SMPLFIT_BM_KNOWN_SHAPE")) t.bm_known_shape = e[0] != '0';
@@ -1947,7 +1949,23 @@ int smplfit_shape_solve_ex_f32(const smplfit_handle* h, const smplfit_shape_solv
                        args->beta_regularizer_reference,
                        args->beta_regularizer_reference ? std::min(args->num_reference_betas, d.S - d.jt.n_kid - d.jt.n_pad) : 0,
                        args->kid_regularizer_reference);
-  launch_center_sort(d, args->target_vertices, args->target_joints, vertex_weights, ws, batch, st);
+  // the batch-major vertex kernels (round 4): streams, transposed GEMM, residual pass + pair-Gram (unit weights) or the
+  // accumulate kernel (vertex weights in the solve / a scale unknown), as one iteration of fit()
+  const bool scaled = o.scale_mode != 0;
+  const bool bm = bm_applies(h) && tune().bm_known_pose && (!vertex_weights || (tune().bm_weighted && (!eff_v || d.S == 10))) &&
+                  (!scaled || (tune().bm_scale && d.S == 10));
+  const int Mp = (int)align_up((size_t)batch, 128);
+  if (bm) {
+    const int nslab = (d.V + kSlabV - 1) / kSlabV;
+    if (eff_v)
+      hipLaunchKernelGGL(k_layout_weights, dim3((d.V + 63) / 64 + 1, Mp / 64), dim3(256), 0, st, d, vertex_weights, ws.wT, batch);
+    hipLaunchKernelGGL(k_layout_targets, dim3(nslab, Mp / 64), dim3(256), (size_t)64 * kSlabRow * 4, st, d, args->target_vertices,
+                       ws.tT, ws.resP, batch, Mp);
+    hipLaunchKernelGGL(k_mean_finish, dim3(Mp / 64), dim3(64 * kMeanWaves), 0, st, d, args->target_joints, ws.resP, ws, batch, Mp,
+                       nslab);
+  } else {
+    launch_center_sort(d, args->target_vertices, args->target_joints, vertex_weights, ws, batch, st);
+  }
   JointStageArgs ja{};
   ja.tj = joints ? ws.tjc : ws.tjreg;  // unused without the joint block
   ja.rj = nullptr;
@@ -1961,12 +1979,22 @@ int smplfit_shape_solve_ex_f32(const smplfit_handle* h, const smplfit_shape_solv
   ja.vertex_sa_closed_form = eff_v ? 0 : 1;
   if (!joints) hipMemsetAsync(ws.tjreg, 0, (size_t)batch * d.J * 3 * 4, st);
   launch_joint_stage(d, ja, ws, batch, st);
-  launch_gemm(d, ws, batch, st);
+  if (bm) {
+    if (int rc2 = launch_gemm(d, ws, batch, st, true)) return rc2;
+    launch_jd_transpose(d, ws, batch, st);
+    if (scaled) launch_accum_w_bm(h, ws, batch, st, eff_v, true);
+    else if (eff_v) launch_accum_w_bm(h, ws, batch, st);
+    else launch_residual_bm(h, ws, batch, st);
+    rc = enqueue_solve(d, ws, batch, o, joints, eff_v, eff_j, joint_weights, (!eff_v && !scaled) ? 1 : 0, use_ref, scaled, st,
+                       scaled);
+  } else {
+    launch_gemm(d, ws, batch, st);
 #define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, batch, eff_v, st)
-  SF_DISPATCH_SKW(d, SF_CALL_ACCUM);
+    SF_DISPATCH_SKW(d, SF_CALL_ACCUM);
 #undef SF_CALL_ACCUM
-  rc = enqueue_solve(d, ws, batch, o, joints, eff_v, eff_j, joint_weights, (!eff_v && use_pair_form()) ? 1 : 0,
-                     use_ref, o.scale_mode != 0, st);
+    rc = enqueue_solve(d, ws, batch, o, joints, eff_v, eff_j, joint_weights, (!eff_v && use_pair_form()) ? 1 : 0,
+                       use_ref, scaled, st);
+  }
   if (rc) return rc;
   // a scaled solve leaves the shape as the reference returns it (undivided, :1277-1283) in beta_out
   hipLaunchKernelGGL(k_emit_solution, dim3((batch + 255) / 256), dim3(256), 0, st, ws,
@@ -1977,7 +2005,14 @@ int smplfit_shape_solve_ex_f32(const smplfit_handle* h, const smplfit_shape_solv
   if (args->joints_out)
     hipLaunchKernelGGL(k_copy, dim3(64), dim3(256), 0, st, ws.rjoints, args->joints_out,
                        (size_t)batch * d.J * 3);
-  if (args->vertices_out) {
+  if (args->vertices_out && bm) {  // the mesh at the solution: forward-only LBS pass + the inverse of the target layout
+    const ShareView sv = share_view(h, sf::kShareLbsAll, batch);
+    const dim3 grid = share_grid(sv, Mp);
+    if (d.S == 11) hipLaunchKernelGGL((k_lbs_partsum_bm<11, 4, true, true>), grid, dim3(64 * kBW), 0, st, d, sv, ws, batch, Mp);
+    else hipLaunchKernelGGL((k_lbs_partsum_bm<10, 4, true, true>), grid, dim3(64 * kBW), 0, st, d, sv, ws, batch, Mp);
+    hipLaunchKernelGGL(k_unlayout_vertices, dim3((d.V + kSlabV - 1) / kSlabV, Mp / 64), dim3(256), (size_t)64 * kSlabRow * 4, st, d,
+                       ws.vpT, args->vertices_out, batch);
+  } else if (args->vertices_out) {
     float* vertices_out = args->vertices_out;
 #define SF_CALL_LBS(S_, KW_) \
   launch_lbs<S_, KW_, 2, false>(d, ws, batch, false, d.S, ws.beta, ws.trans, vertices_out, 0.f, 0.f, st)

@@ -721,10 +721,12 @@ def test_share_beta_goldens(name, model_root, golden, dev, vertex_path):
     assert (back['vertices'] - fw['vertices']).norm(dim=-1).mean().item() < 5e-3
 
 
+@pytest.mark.parametrize('path', ['batch-major', 'wave-per-instance'])
 @pytest.mark.parametrize('name', ['smpl', 'smplx'])
-def test_known_pose_option_goldens(name, model_root, golden, dev):
+def test_known_pose_option_goldens(name, path, model_root, golden, dev, smplfit_env):
     """fit_with_known_pose with share_beta / scale_target / scale_fit / ridge references
     (smplfit_shape_solve_ex_f32) against the reference's fixture, and against the oracle at B = 300."""
+    smplfit_env('SMPLFIT_BM_KNOWN_POSE', '1' if path == 'batch-major' else '0')  # (both vertex paths of the shape solve)
     from smplfitter_amd.pt import BodyFitter
 
     g, gk = golden(name), golden(f'kp_{name}')
