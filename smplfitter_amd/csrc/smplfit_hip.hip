@@ -476,7 +476,7 @@ void launch_template_partsum_bm(const smplfit_handle* h, const Workspace& ws, in
 // One-pass target layout of the batch-major path (k_layout_targets, k_mean_finish, k_template_partsum_bm):
 // ws.tT, ws.mean, ws.tjc and the template part sums ws.psum.  ws.resP serves as the slab-sum scratch.
 void launch_layout_bm(const smplfit_handle* h, const float* tv, const float* tj, const Workspace& ws, int B, hipStream_t st,
-                      const float* vw = nullptr) {
+                      const float* vw = nullptr, bool template_sums = true) {
   const DevModel& d = h->d;
   if (vw)  // vertex weights: their stream first (the template part sums below read it)
     hipLaunchKernelGGL(k_layout_weights, dim3((d.V + 63) / 64 + 1, (int)align_up((size_t)B, 128) / 64), dim3(256), 0, st, d, vw,
@@ -485,7 +485,8 @@ void launch_layout_bm(const smplfit_handle* h, const float* tv, const float* tj,
   hipLaunchKernelGGL(k_layout_targets, dim3(nslab, Mp / 64), dim3(256), (size_t)64 * kSlabRow * 4, st, d, tv, ws.tT,
                      ws.resP, B, Mp);
   hipLaunchKernelGGL(k_mean_finish, dim3(Mp / 64), dim3(64 * kMeanWaves), 0, st, d, tj, ws.resP, ws, B, Mp, nslab);
-  launch_template_partsum_bm(h, ws, B, st, vw != nullptr);
+  // (a warm-started fit takes its first part sums against the posed initial model instead)
+  if (template_sums) launch_template_partsum_bm(h, ws, B, st, vw != nullptr);
 }
 
 // K3' + K3g + K3c of the batch-major path for 10 betas (S = 10) and 10 betas + the kid unknown (S = 11)
@@ -918,14 +919,14 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   const bool bm_base = bm_applies(h) && !o.rotations_only && (!o.scale_mode || (tune().bm_scale && d.S == 10));
   const bool bm = bm_base && (!vw || (tune().bm_weighted && (!eff_v || d.S == 10)));
   if (o.source && !bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "fused conversion: the batch-major path does not apply");
-  // a warm-started fit evaluates its first part sums against the posed model with the wave-per-instance
-  // kernel, which reads the per-instance sorted copy ws.tvs: that copy is produced as well then
-  if (on(0) && (!bm || o.init_pose || o.init_betas)) launch_center_sort(d, tv, tj, vw, ws, B, st);
+  // (a warm-started fit evaluates its first part sums against the posed initial model: on the batch-major path with
+  // the LBS pass of the iterations — until round 4 with the wave-per-instance kernel over a second, sorted copy)
+  if (on(0) && !bm) launch_center_sort(d, tv, tj, vw, ws, B, st);
   if (!on(0)) {
   } else if (bm && o.source) {
     if (int rc = launch_convert_source(*o.source, d, ws, B, st)) return rc;
   } else if (bm) {
-    launch_layout_bm(h, tv, tj, ws, B, st, vw);
+    launch_layout_bm(h, tv, tj, ws, B, st, vw, !(o.init_pose || o.init_betas));
   }
   const float* tj_rot = ws.tjc;
   if (!joints) {  // regressed target joints from the centred vertices (bodyfitter.py:1342-1344)
@@ -961,7 +962,14 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     fa.nb = d.S;
     fa.joints = ws.rjoints;
     fa.orient = ws.G;
-    if (on(0)) {
+    if (on(0) && bm) {
+      hipLaunchKernelGGL(k_forward_joint, dim3(B), dim3(64), joint_lds(d), st, d, fa, ws);
+      if (int rc = launch_gemm(d, ws, B, st, true)) return rc;
+      launch_jd_transpose(d, ws, B, st);
+#define SF_CALL_LBS(S_, KW_) launch_lbs_bm<S_, KW_>(h, ws, B, st, !joints, false, vweighted)
+      SF_DISPATCH_SKW(d, SF_CALL_LBS);
+#undef SF_CALL_LBS
+    } else if (on(0)) {
       hipLaunchKernelGGL(k_forward_joint, dim3(B), dim3(64), joint_lds(d), st, d, fa, ws);
       launch_gemm(d, ws, B, st);
 #define SF_CALL_LBS(S_, KW_) \
