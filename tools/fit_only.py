@@ -1,4 +1,4 @@
-"""N default fits of a batch and nothing else (for counter passes): python tools/fit_only.py <B> <nfits> [smpl|smplx] [weights]"""
+"""N default fits of a batch and nothing else (for counter passes): python tools/fit_only.py <B> <nfits> [smpl|smplx] [weights|kid]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,13 +10,13 @@ kind = sys.argv[3] if len(sys.argv) > 3 else 'smpl'
 dev = torch.device('cuda:0')
 root = synth.ensure_model_root(kinds=(kind,))
 model = BodyModel(kind, 'neutral', model_root=f'{root}/{kind}', num_betas=10, device=dev)
-fitter = BodyFitter(model)
+fitter = BodyFitter(model, enable_kid=len(sys.argv) > 4 and sys.argv[4] == 'kid')
 J = model.num_joints
 rs = np.random.RandomState(42)
 t = lambda a: torch.from_numpy(a.astype(np.float32)).to(dev)
 fw = model(t(rs.randn(B, 3 * J) * 0.1), t(rs.randn(B, 10) * 0.5), t(rs.randn(B, 3)))
 tv, tj = fw['vertices'].contiguous(), fw['joints'].contiguous()
-ws = torch.empty(model._native(dev).workspace_bytes(B), dtype=torch.uint8, device=dev)
+ws = torch.empty(model._native(dev, kid=len(sys.argv) > 4 and sys.argv[4] == 'kid').workspace_bytes(B), dtype=torch.uint8, device=dev)
 kw = {}
 if len(sys.argv) > 4 and sys.argv[4] == 'weights':
     kw = dict(vertex_weights=torch.rand(B, model.num_vertices, device=dev) + 0.5, joint_weights=torch.rand(B, J, device=dev) + 0.5)
