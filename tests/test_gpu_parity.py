@@ -288,8 +288,9 @@ def test_full_size_properties(name, B, model_root, golden, dev, vertex_path):
         assert torch.equal(r[k][s], r3[k]), k
     s = slice(B // 2 - 5, B // 2 + 6)
     r4 = f.fit(tv[s], tj[s], num_iter=3, beta_regularizer=1.0, requested_keys=['pose_rotvecs'])
-    # (pose on the thin-finger SMPL-X fixture: ill-conditioned in the reference itself, see test_fit_goldens)
-    for k, tol in (('pose_rotvecs', 5e-3 if name == 'smplx' else 1e-4), ('shape_betas', 1e-4), ('trans', 1e-5)):
+    # (pose: the fp32 floor of the algorithm, 3e-4 as in test_fit_goldens; the thin-finger SMPL-X fixture is
+    # ill-conditioned in the reference itself)
+    for k, tol in (('pose_rotvecs', 5e-3 if name == 'smplx' else 3e-4), ('shape_betas', 1e-4), ('trans', 1e-5)):
         assert (r[k][s] - r4[k]).abs().max().item() < tol, k
     # orientations are proper rotations
     R = r['orientations']
