@@ -770,6 +770,10 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
       t.reg_start.push_back((int)t.reg_slot.size());
     }
     t.has_regressor = true;
+    // the slots the regressor reads, flagged in the spare float behind the shapedirs of their batch-major record: a
+    // joints-omitted fit writes the posed vertex back only there (k_lbs_partsum_bm, WRITE_V)
+    if (!t.brec.empty() && t.brec_w() > 3 * S)
+      for (int slot : t.reg_slot) t.brec[(size_t)slot * t.brec_stride() + 3 * S] = 1.f;
   }
   return "";
 }

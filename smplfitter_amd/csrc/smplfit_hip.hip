@@ -545,17 +545,19 @@ void launch_accum_w_bm(const smplfit_handle* h, const Workspace& ws, int B, hipS
 // (bodyfitter.py:1505-1517) — only those parts' slots are visited, the other rows of ws.psum become zero.
 template <int S, int KW>
 void launch_lbs_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStream_t st, bool write_v = false,
-                   bool adj_only = false, bool weighted = false) {
+                   bool adj_only = false, bool weighted = false, bool write_all = false) {
   const DevModel& d = h->d;
   const int Mp = (int)align_up((size_t)B, 128);
   const size_t lds = (size_t)tune().bm_lds_kb * 1024;
   const ShareView sv = share_view(h, write_v ? sf::kShareLbsAll : adj_only ? sf::kShareLbsAdj : sf::kShareLbsUsed, B);
   if constexpr (KW == 4 && S <= 12) {  // what bm_applies admits (10 betas with or without the kid unknown)
     if (write_v) {
+      // (write_all: every posed vertex — the alignment sums of a known-shape fit; else the slots the regressor reads)
+      const int wa = write_all ? 1 : 0;
       if (weighted)
-        hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4, true, false, true>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp);
+        hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4, true, false, true>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp, wa);
       else
-        hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4, true>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp);
+        hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4, true>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp, wa);
       hipLaunchKernelGGL(k_regress_joints_bm<false>, dim3(Mp / 64, d.J), dim3(64), 0, st, d, ws.vpT, nullptr, ws.rjreg, B);
     } else if (weighted) {
       hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4, false, false, true>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp);
@@ -1138,7 +1140,7 @@ int run_fit_known_shape(const smplfit_handle* h, const float* betas, int nb, con
       launch_jd_transpose(d, ws, B, st);
       // the posed mesh is kept (in place, ws.vpT) where it is read: regressed joints, and the alignment sums behind the
       // last pass
-#define SF_CALL_LBS(S_, KW_) launch_lbs_bm<S_, KW_>(h, ws, B, st, !joints || it == o.num_iter, false, vweighted)
+#define SF_CALL_LBS(S_, KW_) launch_lbs_bm<S_, KW_>(h, ws, B, st, !joints || it == o.num_iter, false, vweighted, it == o.num_iter)
       SF_DISPATCH_SKW(d, SF_CALL_LBS);
 #undef SF_CALL_LBS
     } else {

@@ -1,4 +1,4 @@
-"""N default fits of a batch and nothing else (for counter passes): python tools/fit_only.py <B> <nfits> [smpl|smplx] [weights|kid]"""
+"""N default fits of a batch and nothing else (for counter passes): python tools/fit_only.py <B> <nfits> [smpl|smplx] [weights|kid|nojoints]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -22,5 +22,5 @@ if len(sys.argv) > 4 and sys.argv[4] == 'weights':
     kw = dict(vertex_weights=torch.rand(B, model.num_vertices, device=dev) + 0.5, joint_weights=torch.rand(B, J, device=dev) + 0.5)
 torch.cuda.synchronize()
 for _ in range(n):
-    fitter.fit(tv, tj, **kw, num_iter=3, beta_regularizer=1.0, requested_keys=['pose_rotvecs', 'shape_betas', 'trans'], _workspace=ws)
+    fitter.fit(tv, None if (len(sys.argv) > 4 and sys.argv[4] == 'nojoints') else tj, **kw, num_iter=3, beta_regularizer=1.0, requested_keys=['pose_rotvecs', 'shape_betas', 'trans'], _workspace=ws)
 torch.cuda.synchronize()
