@@ -334,8 +334,9 @@ def test_workspace_guards(name, model_root, golden, dev):
     the per-call workspace is embedded between two 1 MB guard regions whose byte pattern must survive every call, and
     is itself filled with NaN bit patterns before each call — a kernel reading a cell nobody wrote first would carry
     NaN into the results, which must be finite and bit-identical to a run on a zeroed workspace.  Covers the default
-    two-chunk fit with a partial last instance block, the kid unknown, joints omitted, vertex weights (wave-per-
-    instance kernels) and a warm start."""
+    fit with a partial last instance block, the kid unknown, joints omitted, vertex weights (the accumulate kernel), a
+    warm start, the scale options (the accumulate kernel's extras), share_beta (the two-level reduction), a small batch
+    (the fine cell tables), fit_with_known_shape (alignment kernels) and fit_with_known_pose (shape solve entry)."""
     from smplfitter_amd.pt import BodyFitter
 
     g = golden(name)
@@ -352,12 +353,24 @@ def test_workspace_guards(name, model_root, golden, dev):
                         joint_weights=torch.rand(B, m.num_joints, device=dev) + 0.5)),
         (f, False, dict(num_iter=2, initial_pose_rotvecs=torch.zeros(B, 3 * m.num_joints, device=dev),
                         initial_shape_betas=torch.zeros(B, 10, device=dev))),
+        (f, False, dict(num_iter=2, scale_target=True)),
+        (f, False, dict(num_iter=2, scale_fit=True, vertex_weights=torch.rand(B, m.num_vertices, device=dev) + 0.5,
+                        joint_weights=torch.rand(B, m.num_joints, device=dev) + 0.5)),
+        (f, False, dict(num_iter=2, share_beta=True)),
+        (f, False, dict(num_iter=2, beta_regularizer=1.0, _rows=37)),
+        (f, False, dict(_call='known_shape', num_iter=2, scale_fit=True)),
+        (f, True, dict(_call='known_shape', num_iter=1, target_joints=None,
+                       vertex_weights=torch.rand(B, m.num_vertices, device=dev) + 0.5)),
+        (f, False, dict(_call='known_pose')),
     ]
+    zeros_pose = torch.zeros(B, 3 * m.num_joints, device=dev)
+    zeros_betas = torch.zeros(B, 10, device=dev)
     for fitter, no_joints, kw in cases:
         kw = dict(kw)
         kw.pop('target_joints', None)
+        call, rows = kw.pop('_call', 'fit'), kw.pop('_rows', B)
         h = m._native(dev, kid=fitter.enable_kid)
-        n = h.workspace_bytes(B)
+        n = h.workspace_bytes(rows)
         buf = torch.empty(n + 2 * guard, dtype=torch.uint8, device=dev)
         ws = buf[guard:guard + n]
         assert ws.data_ptr() % 256 == 0
@@ -368,7 +381,20 @@ def test_workspace_guards(name, model_root, golden, dev):
                 ws.zero_()
             else:
                 ws.view(torch.int32).fill_(0x7FC00000 | 0x1234)  # quiet NaN pattern in every float / half a double
-            r = fitter.fit(tv, None if no_joints else tj, _workspace=ws, **kw)
+            kwr = {k: (v[:rows] if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
+            tjr = None if no_joints else tj[:rows]
+            if call == 'fit':
+                r = fitter.fit(tv[:rows], tjr, _workspace=ws, **kwr)
+            else:  # (these entries take the model's cached workspace: it is swapped for the guarded one)
+                keep = m._workspace
+                m._workspace = lambda h_, B_, device_, ws=ws: ws
+                try:
+                    if call == 'known_shape':
+                        r = fitter.fit_with_known_shape(zeros_betas[:rows], tv[:rows], tjr, **kwr)
+                    else:
+                        r = fitter.fit_with_known_pose(zeros_pose[:rows], tv[:rows], tjr, **kwr)
+                finally:
+                    m._workspace = keep
             torch.cuda.synchronize()
             assert bool((buf[:guard] == 0xA5).all()) and bool((buf[guard + n:] == 0xA5).all()), 'guard region written'
             out[fill] = {k: v.clone() for k, v in r.items()}
