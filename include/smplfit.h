@@ -73,7 +73,7 @@ const char* smplfit_last_error(void);
 const char* smplfit_version(void);
 /* Version of this header's structs and entry points; bumped whenever a struct gains a field or a signature
  * changes.  A client compares it with the SMPLFIT_ABI_VERSION it was built against before the first call. */
-#define SMPLFIT_ABI_VERSION 4
+#define SMPLFIT_ABI_VERSION 5
 int smplfit_abi_version(void);
 
 typedef struct smplfit_info {
@@ -88,7 +88,15 @@ typedef struct smplfit_info {
   int32_t has_device;
   int32_t gemm_vgprs;          /* registers per lane of the split-bf16 GEMM kernels as built (0 without a device):
                                   they must own whole CUs (>= 256); below that the fp32-MFMA GEMM runs instead  */
+  int32_t vertex_path;         /* which kernels the vertex passes of a default (unit-weight) fit run on:
+                                  SMPLFIT_PATH_BATCH_MAJOR (lane = instance, the fast path), SMPLFIT_PATH_WAVE
+                                  (one wave per instance: 16 betas, small subsets, non-normalised weights — about
+                                  0.4x the rate) or SMPLFIT_PATH_GENERAL (any number of betas / skinning weights) */
+  int32_t share_fallback;      /* bit k: cell table k (see smplfit_get_share_table) is a copy of a wider or coarser
+                                  one because its own domain was too small for its cells; 0xffff: the model has
+                                  no cell tables at all (SMPLFIT_PATH_WAVE)                                        */
 } smplfit_info;
+enum smplfit_vertex_path { SMPLFIT_PATH_WAVE = 0, SMPLFIT_PATH_BATCH_MAJOR = 1, SMPLFIT_PATH_GENERAL = 2 };
 int smplfit_get_info(const smplfit_handle* h, smplfit_info* info);
 
 /* Introspection of the host tables, for tests.  Copies up to cap int32 entries, sets *n. */

@@ -23,7 +23,7 @@ SMPLFIT_ERR_UNSUPPORTED = -2
 SMPLFIT_ERR_WORKSPACE = -3
 SMPLFIT_ERR_HIP = -4
 SMPLFIT_CREATE_HOST_ONLY = 1
-SMPLFIT_ABI_VERSION = 4  # include/smplfit.h; checked against smplfit_abi_version() when the library is loaded
+SMPLFIT_ABI_VERSION = 5  # include/smplfit.h; checked against smplfit_abi_version() when the library is loaded
 
 TABLE_IDS = dict(
     part_assignment=0, sort_perm=1, part_type=2, fk_order=3, fk_level_start=4, adj_flag=5,
@@ -136,6 +136,7 @@ class Info(C.Structure):
         for n in (
             'num_vertices', 'num_joints', 'num_betas', 'has_kid', 'padded_vertices', 'num_used_vertices',
             'skin_width', 'num_segments', 'num_fk_levels', 'adj_last_level', 'has_device', 'gemm_vgprs',
+            'vertex_path', 'share_fallback',
         )
     ]  # fmt: skip
 

@@ -164,11 +164,31 @@ void build_share_tables(HostTables& t) {
   for (int k = 0; k < 2 * kShareKinds; ++k) {
     if (k < kShareFine) build_share_table(t, k, t.shares[k], SMPLFIT_CELL_STEPS, SMPLFIT_CELL_CAP);
     else build_share_table(t, k - kShareFine, t.shares[k], kFineCellSteps, kFineCellCap);
-    if (t.shares[k].ncells == 0) {  // a domain too small for its cells: the model stays on the wave-per-instance kernels
+  }
+  // A domain too small for its cells (ncells == 0) falls back PER KIND: the adjustable-parts table to the used-parts
+  // table of the same granularity (a superset: the extra part sums are not read by the refinement), a fine table to its
+  // coarse one (walked by the split combines all the same).  Only a model whose coarse residual / all-slots / used-parts
+  // table is empty stays on the wave-per-instance kernels.  HostTables::share_fallback (smplfit_info) says which.
+  t.share_fallback = 0;
+  for (int g = 0; g < 2; ++g) {
+    ShareTable& adj = t.shares[g * kShareFine + kShareLbsAdj];
+    const ShareTable& used = t.shares[g * kShareFine + kShareLbsUsed];
+    if (adj.ncells == 0 && used.ncells != 0) {
+      adj = used;
+      t.share_fallback |= 1 << (g * kShareFine + kShareLbsAdj);
+    }
+  }
+  for (int k = 0; k < kShareKinds; ++k)
+    if (t.shares[kShareFine + k].ncells == 0 && t.shares[k].ncells != 0) {
+      t.shares[kShareFine + k] = t.shares[k];
+      t.share_fallback |= 1 << (kShareFine + k);
+    }
+  for (int k = 0; k < 2 * kShareKinds; ++k)
+    if (t.shares[k].ncells == 0) {
+      t.share_fallback = 0xffff;  // no batch-major tables at all
       t.shares.clear();
       return;
     }
-  }
 }
 
 int pick_share_mult(const HostTables& t, int kind, int nblocks, int slots, int wg_waves) {
@@ -748,11 +768,12 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
 
   // ---- sparse joint regressor over sorted slots ----
   t.has_regressor = false;
-  t.reg_start.assign(1, 0);
+  t.reg_start.assign(J + 1, 0);  // (no regressor: J empty rows, so that a stray reader finds valid loop bounds)
   t.reg_slot.clear();
   t.reg_val.clear();
   t.reg_rowsum.assign(J, 0.f);
   if (d.J_regressor_post_lbs && d.regressor_num_vertices == V) {
+    t.reg_start.assign(1, 0);
     std::vector<int> slot_of(V);
     for (int i = 0; i < V; ++i) slot_of[order[i]] = i;
     for (int j = 0; j < J; ++j) {

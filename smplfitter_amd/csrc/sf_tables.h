@@ -192,6 +192,7 @@ struct HostTables {
   // batch-major kernels: the pieces of the sorted slots and the cell tables cut from them, one per ShareKind
   std::vector<VertexPiece> vpieces;
   std::vector<ShareTable> shares;  // (2 kShareKinds: coarse, fine), empty when the model has no batch-major tables
+  int share_fallback = 0;  // bit k: shares[k] is a copy of a wider / coarser table (build_share_tables); 0xffff: no tables
   // the batch-major pair-Gram kernel reads rows of shape values as aligned register PAIRS: its copies of the
   // constants have the y axis padded to an even length SE = S rounded up to 2 (the padding is zero)
   std::vector<float> pair_E;     // (np, 9 [a a'], ng_pad()) symmetrised pair_c1 over the upper triangle (i <= i2, row-major)

@@ -237,6 +237,16 @@ struct Workspace {
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Work units of k_pair_gram_bm (kernels_bm.inc): every joint twice + chunks of kPgPairs joint pairs; a workgroup of
+// kPgWaves waves takes kPgWaves units and writes ONE upper triangle to ws.gramP.  Shared by the workspace carve, the
+// launch and the combine kernels.
+#ifndef SMPLFIT_PG_PAIRS
+#define SMPLFIT_PG_PAIRS 2
+#endif
+constexpr int kPgWaves = 8, kPgPairs = SMPLFIT_PG_PAIRS;
+constexpr int pair_gram_units(int J, int npairs) { return 2 * J + (npairs + kPgPairs - 1) / kPgPairs; }
+constexpr int pair_gram_workgroups(int J, int npairs) { return (pair_gram_units(J, npairs) + kPgWaves - 1) / kPgWaves; }
 constexpr int kAccExtrasHost = 16;  // (= kAccExtras of kernels_bm.inc: the extras of the scaled solve behind a cell record)
 
 #ifndef SMPLFIT_SLAB
@@ -310,9 +320,9 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w, bool fwd_
     ws.wT = (float*)take(t.shares.empty() ? 0 : Mp * Vp * 4);
     ws.accP = (float*)take(acc_cells * (NE1 + kAccExtrasHost) * Mp * 4);
   }
-  {  // k_pair_gram_bm: one upper triangle per workgroup of 8 units (2 per joint + chunks of 4 pairs), NG <= NE
-    const size_t units = 2 * J + (t.pair_c3.size() + 3) / 4;
-    ws.gramP = (float*)take((units + 7) / 8 * (NE1 - 1) * Mp * 4);
+  {  // k_pair_gram_bm: one upper triangle (NG rows) per workgroup of its launch (pair_gram_workgroups: the same
+     // constants as the launch and the combine kernels)
+    ws.gramP = (float*)take((size_t)pair_gram_workgroups((int)J, (int)t.pair_c3.size()) * sf::ne_ng((int)S) * Mp * 4);
   }
   ws.jdT = (float*)take(Mp * align_up((size_t)J * sf::jd_stride(S), 64) * 4, true);
   if (w) *w = ws;
@@ -499,8 +509,7 @@ void launch_residual_bm_s(const smplfit_handle* h, const Workspace& ws, int B, h
     hipLaunchKernelGGL((k_residual_bm<S>), share_grid(sv, Mp), dim3(64 * kBW),
                        std::max(kResidualLds, (size_t)tune().bm_lds_kb * 1024), st, d, sv, ws, B, Mp);
   if (which & 2) {
-    const int units = 2 * d.J + (d.jt.np + kPgPairs - 1) / kPgPairs;
-    hipLaunchKernelGGL((k_pair_gram_bm<S>), dim3((units + kPgWaves - 1) / kPgWaves, Mp / 64), dim3(64 * kPgWaves), 0, st, d, ws, B, Mp);
+    hipLaunchKernelGGL((k_pair_gram_bm<S>), dim3(pair_gram_workgroups(d.J, d.jt.np), Mp / 64), dim3(64 * kPgWaves), 0, st, d, ws, B, Mp);
   }
   if ((which & 4) && sv.fine)
     hipLaunchKernelGGL((k_gram_combine_split<S, 16>), dim3(Mp / 64, S + 3 + 3 * d.J + sf::ne_ng(S)), dim3(64 * 16), 0,
@@ -545,7 +554,7 @@ void launch_accum_w_bm(const smplfit_handle* h, const Workspace& ws, int B, hipS
 // (bodyfitter.py:1505-1517) — only those parts' slots are visited, the other rows of ws.psum become zero.
 template <int S, int KW>
 void launch_lbs_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStream_t st, bool write_v = false,
-                   bool adj_only = false, bool weighted = false, bool write_all = false) {
+                   bool adj_only = false, bool weighted = false, bool write_all = false, int regress = -1) {
   const DevModel& d = h->d;
   const int Mp = (int)align_up((size_t)B, 128);
   const size_t lds = (size_t)tune().bm_lds_kb * 1024;
@@ -558,7 +567,11 @@ void launch_lbs_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStrea
         hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4, true, false, true>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp, wa);
       else
         hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4, true>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp, wa);
-      hipLaunchKernelGGL(k_regress_joints_bm<false>, dim3(Mp / 64, d.J), dim3(64), 0, st, d, ws.vpT, nullptr, ws.rjreg, B);
+      // regress: the regressed reference joints are consumed (joints-omitted fits).  A known-shape fit WITH target
+      // joints keeps the posed mesh for its alignment sums only; and a model without a regressor has none to apply
+      const bool do_regress = (regress < 0 ? true : regress != 0) && h->t.has_regressor;
+      if (do_regress)
+        hipLaunchKernelGGL(k_regress_joints_bm<false>, dim3(Mp / 64, d.J), dim3(64), 0, st, d, ws.vpT, nullptr, ws.rjreg, B);
     } else if (weighted) {
       hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4, false, false, true>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp);
     } else {
@@ -784,26 +797,42 @@ inline bool stage_half(const DevModel& d, int bit, int B) {
 
 void launch_joint_stage(const DevModel& d, JointStageArgs ja, const Workspace& ws, int B, hipStream_t st) {
   ja.B = B;
-  if (stage_half(d, 1, B))
-    hipLaunchKernelGGL(k_joint_stage<32>, dim3((B + 1) / 2), dim3(64), 2 * joint_lds(d), st, d, ja, ws);
-  else
+  ja.b0 = 0;
+  if (stage_half(d, 1, B)) {
+    hipLaunchKernelGGL(k_joint_stage<32>, dim3(B / 2), dim3(64), 2 * joint_lds(d), st, d, ja, ws);
+    if (B & 1) {  // the odd last instance: a launch of its own (no wave works on one instance twice)
+      ja.b0 = B - 1;
+      hipLaunchKernelGGL(k_joint_stage<64>, dim3(1), dim3(64), joint_lds(d), st, d, ja, ws);
+    }
+  } else {
     hipLaunchKernelGGL(k_joint_stage<64>, dim3(B), dim3(64), joint_lds(d), st, d, ja, ws);
+  }
 }
 void launch_refine(const DevModel& d, RefineArgs ra, const Workspace& ws, int B, hipStream_t st) {
   ra.B = B;
-  if (stage_half(d, 4, B))
-    hipLaunchKernelGGL(k_refine_epilogue<32>, dim3((B + 1) / 2), dim3(64), 2 * joint_lds(d, 1), st, d, ra, ws);
-  else
+  ra.b0 = 0;
+  if (stage_half(d, 4, B)) {
+    hipLaunchKernelGGL(k_refine_epilogue<32>, dim3(B / 2), dim3(64), 2 * joint_lds(d, 1), st, d, ra, ws);
+    if (B & 1) {
+      ra.b0 = B - 1;
+      hipLaunchKernelGGL(k_refine_epilogue<64>, dim3(1), dim3(64), joint_lds(d, 1), st, d, ra, ws);
+    }
+  } else {
     hipLaunchKernelGGL(k_refine_epilogue<64>, dim3(B), dim3(64), joint_lds(d, 1), st, d, ra, ws);
+  }
 }
 void launch_shape_solve(const DevModel& d, const Workspace& ws, int B, hipStream_t st, float beta_reg, float beta_reg2,
                         float kid_reg, int pair_form, int use_ref, int mode = 0) {
-  if (stage_half(d, 2, B))
-    hipLaunchKernelGGL(k_shape_solve<32>, dim3((B + 1) / 2), dim3(64), 2 * solve_lds(d), st, d, ws, B, beta_reg,
-                       beta_reg2, kid_reg, pair_form, use_ref, mode);
-  else
+  if (stage_half(d, 2, B)) {
+    hipLaunchKernelGGL(k_shape_solve<32>, dim3(B / 2), dim3(64), 2 * solve_lds(d), st, d, ws, B, beta_reg,
+                       beta_reg2, kid_reg, pair_form, use_ref, mode, 0);
+    if (B & 1)
+      hipLaunchKernelGGL(k_shape_solve<64>, dim3(1), dim3(64), solve_lds(d), st, d, ws, B, beta_reg, beta_reg2,
+                         kid_reg, pair_form, use_ref, mode, B - 1);
+  } else {
     hipLaunchKernelGGL(k_shape_solve<64>, dim3(B), dim3(64), solve_lds(d), st, d, ws, B, beta_reg, beta_reg2,
-                       kid_reg, pair_form, use_ref, mode);
+                       kid_reg, pair_form, use_ref, mode, 0);
+  }
 }
 
 int post_launch_check() {
@@ -1140,7 +1169,7 @@ int run_fit_known_shape(const smplfit_handle* h, const float* betas, int nb, con
       launch_jd_transpose(d, ws, B, st);
       // the posed mesh is kept (in place, ws.vpT) where it is read: regressed joints, and the alignment sums behind the
       // last pass
-#define SF_CALL_LBS(S_, KW_) launch_lbs_bm<S_, KW_>(h, ws, B, st, !joints || it == o.num_iter, false, vweighted, it == o.num_iter)
+#define SF_CALL_LBS(S_, KW_) launch_lbs_bm<S_, KW_>(h, ws, B, st, !joints || it == o.num_iter, false, vweighted, it == o.num_iter, joints ? 0 : 1)
       SF_DISPATCH_SKW(d, SF_CALL_LBS);
 #undef SF_CALL_LBS
     } else {
@@ -1679,6 +1708,8 @@ int smplfit_get_info(const smplfit_handle* h, smplfit_info* info) {
   info->adj_last_level = t.adj_last_level;
   info->has_device = h->has_device ? 1 : 0;
   info->gemm_vgprs = h->gemm_vgprs;
+  info->vertex_path = bm_applies(h) ? SMPLFIT_PATH_BATCH_MAJOR : SMPLFIT_PATH_WAVE;
+  info->share_fallback = t.share_fallback;
   return SMPLFIT_OK;
 }
 

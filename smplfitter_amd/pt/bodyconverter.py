@@ -176,9 +176,8 @@ class BodyConverter(nn.Module):
                 _lib.check(_lib.load().smplfit_convert_f32(plan.ptr, C.byref(args)))
             except NotImplementedError:
                 # the plan was made while the batch-major kernels applied; the tuning options have been reloaded since
-                # (SMPLFIT_BM=0, SMPLFIT_GEMM=f32): forget the plan, take the forward + transfer + fit calls
-                idx = device.index if device.index is not None else torch.cuda.current_device()
-                self._plans[idx] = None
+                # (SMPLFIT_BM=0, SMPLFIT_GEMM=f32): THIS call takes the forward + transfer + fit calls.  The plan is
+                # kept — it is valid again as soon as the options are restored
                 return None
         return out
 
