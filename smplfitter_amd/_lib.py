@@ -20,6 +20,7 @@ LIB_PATH = os.getenv('SMPLFIT_LIB') or osp.join(_HERE, 'libsmplfit_hip.so')
 SMPLFIT_OK = 0
 SMPLFIT_ERR_BAD_ARG = -1
 SMPLFIT_ERR_UNSUPPORTED = -2
+SMPLFIT_PATH_WAVE, SMPLFIT_PATH_BATCH_MAJOR, SMPLFIT_PATH_GENERAL = 0, 1, 2  # smplfit_info.vertex_path
 SMPLFIT_ERR_WORKSPACE = -3
 SMPLFIT_ERR_HIP = -4
 SMPLFIT_CREATE_HOST_ONLY = 1

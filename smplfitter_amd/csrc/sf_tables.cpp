@@ -222,12 +222,17 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
   // The kernels are instantiated for 10 and 16 betas (+ the kid unknown): any other count is padded up with zero
   // shape directions, which the solve pins to zero with a unit ridge (sf::solve_stage); the caller sees its own
   // num_betas everywhere (reference: BodyModel(num_betas=...) accepts any count, bodymodel.py:60-76).
-  const int nb = d.num_betas, nb_pad = nb <= 10 ? 10 : 16;
-  if (nb > 16) {
-    *unsupported = true;
-    return "smplfit_create: more than 16 betas is not supported";
-  }
+  // More than 16 betas (the reference takes any count, default: every column of the file, common.py:223, 381-385; its
+  // _fit_shape_general, bodyfitter.py:1104-1319) or more than 8 non-zero skinning weights per vertex (the reference
+  // blends with the dense (V, J) matrix, :1000-1003): the GENERAL path — the same stages with their scratch in global
+  // memory and vertex kernels with run-time loops over the unknowns and the weights (kernels_gen.inc).  No padding there.
+  const int nb = d.num_betas, nb_pad = nb <= 10 ? 10 : (nb <= 16 ? 16 : nb);
+  bool general = nb > 16;
   const int n_pad = nb_pad - nb;
+  if (nb_pad + n_kid > 1023) {  // (kGenMaxS of kernels_gen.inc)
+    *unsupported = true;
+    return "smplfit_create: more than 1023 shape unknowns";
+  }
   const int S = nb_pad + n_kid;  // the kid blend shape is one more shape direction (the last)
   // shape directions with the kid column appended (bodyfitter.py:52-58, :1139-1149)
   std::vector<float> shapedirs_ext((size_t)V * 3 * S, 0.f), jshapedirs_ext((size_t)J * 3 * S, 0.f);
@@ -361,11 +366,13 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
     t.part_assignment[v] = best;
     max_nnz = std::max(max_nnz, nnz);
   }
-  if (max_nnz > 8) {
+  if (max_nnz > 8) general = true;
+  if (max_nnz > 64) {
     *unsupported = true;
-    return "smplfit_create: more than 8 non-zero skinning weights per vertex";
+    return "smplfit_create: more than 64 non-zero skinning weights per vertex";
   }
-  t.KW = max_nnz <= 4 ? 4 : 8;
+  t.general = general;
+  t.KW = max_nnz <= 4 ? 4 : (max_nnz <= 8 ? 8 : round_up(max_nnz, 4));
 
   // ---- sorted slots: used parts first (by part id, stable), then the rest ----
   std::vector<int> order(V);
@@ -406,6 +413,7 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
   t.vt.assign((size_t)3 * Vp, 0.f);
   t.dm.assign((size_t)3 * Vp, 0.f);
   t.sd.assign((size_t)3 * S * Vp, 0.f);
+  t.sdg.assign(general ? (size_t)Vp * 3 * S : 0, 0.f);  // general path: vertex-major (Vp, 3, S) rows
   t.widx.assign((size_t)(t.KW / 4) * Vp, 0u);
   t.wval.assign((size_t)t.KW * Vp, 0.f);
   t.pdT.assign((size_t)t.Kp * 3 * Vp, 0.f);
@@ -442,9 +450,19 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
       }
       t.pdT[(size_t)kpos(P) * 3 * Vp + (size_t)c * Vp + i] = vtc;  // bias row (feature P == 1)
       t.dm[(size_t)c * Vp + i] = wsum * acc;
-      for (int s = 0; s < S; ++s)
+      for (int s = 0; s < S; ++s) {
         t.sd[(size_t)(c * S + s) * Vp + i] = shapedirs[((size_t)v * 3 + c) * S + s];
+        if (general) t.sdg[((size_t)i * 3 + c) * S + s] = shapedirs[((size_t)v * 3 + c) * S + s];
+      }
     }
+  }
+  // part-aligned tiles over ALL slots (the general path's vertex passes that visit every vertex)
+  t.segments_all.clear();
+  for (int i = 0; i < V;) {
+    int p = t.slot_part[i], e = i;
+    while (e < V && t.slot_part[e] == p) ++e;
+    for (int s0 = i; s0 < e; s0 += kTile) t.segments_all.push_back({s0, std::min(kTile, e - s0), p});
+    i = e;
   }
   {
     const int N = 3 * Vp, Kp = t.Kp, ntile = N / 32;
@@ -492,7 +510,8 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
   }
   t.pdB2.clear();  // built on demand for the device (build_tiled_gemm_images)
   t.kc32 = 0;
-  {
+  t.cpackA.clear(); t.cpackB.clear(); t.brec.clear(); t.vpieces.clear(); t.shares.clear();
+  if (!general) {
     const int cs = t.cstride();
     auto pack = [&](float* dst, int slot) {  // one vertex record
       for (int c = 0; c < 3; ++c)
@@ -589,7 +608,8 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
   }
 
   // closed-form SA constants: sum over ALL vertices (the Gramian runs over every vertex)
-  {
+  t.cs_joint.clear(); t.cw_joint.clear();
+  if (!general) {
     std::vector<double> cs((size_t)J * 3 * S, 0.0), cw(J, 0.0);
     for (int v = 0; v < V; ++v)
       for (int j = 0; j < J; ++j) {
@@ -605,7 +625,9 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
   }
 
   // ---- pair-Gram constants (double accumulation, stored fp32) ----
-  {
+  t.pair_j.clear(); t.pair_c1.clear(); t.pair_c2.clear(); t.pair_c3.clear(); t.diag_g0.clear(); t.diag_c2.clear();
+  t.diag_c3.clear(); t.pair_E.clear(); t.jn_start.clear(); t.jn.clear(); t.pair_c2e.clear(); t.diag_c2e.clear();
+  if (!general) {  // (O(pairs x 9 x S^2): built for the kernels that use them only)
     std::vector<int> pid((size_t)J * J, -1);
     std::vector<std::pair<int, int>> plist;
     for (int v = 0; v < V; ++v) {
@@ -706,8 +728,9 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
   }
 
   // ---- tiles of the residual kernel: part-aligned over all slots, <= 16 distinct joints ----
-  {
-    t.gtiles.clear();
+  t.gtiles.clear();
+  t.gblob.clear();
+  if (!general) {
     for (int i = 0; i < V;) {
       const int p = t.slot_part[i];
       int e = i;

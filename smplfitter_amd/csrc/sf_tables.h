@@ -119,6 +119,9 @@ struct HostTables {
   float wsum_dev = 0.f;
   bool smpl_family = false;
   bool has_regressor = false;
+  // more than 16 betas or more than 8 skinning weights per vertex: the GENERAL path (kernels_gen.inc) — run-time loops
+  // over the unknowns / the weights, stage scratch in global memory; none of the S-templated tables below is built
+  bool general = false;
 
   // kinematic tree
   std::vector<int32_t> parents;         // (J) parents[0] = 0 here ("parents_with_root")
@@ -143,6 +146,8 @@ struct HostTables {
   std::vector<float> vt;        // (3,Vp)  v_template
   std::vector<float> dm;        // (3,Vp)  default mesh = forward(zero pose, zero betas)
   std::vector<float> sd;        // (3*S,Vp) shapedirs, row index c*S+s
+  std::vector<float> sdg;       // (Vp,3,S) the same vertex-major (general path only)
+  std::vector<Segment> segments_all;  // part-aligned tiles over [0, V)
   std::vector<uint32_t> widx;   // (KW/4, Vp) 4 joint ids per word, byte k = k-th pair
   std::vector<float> wval;      // (KW, Vp)
   std::vector<float> pdT;       // (Kp, 3*Vp) posedirs, K-major, rows in rp_pos() (parity-major) order; row rp_pos(P) = v_template

@@ -77,6 +77,11 @@ struct DevModel {
   const float* brec;          // (Vp, brec_stride) per-slot records: shapedirs + 4 weights in the piece's joint order
   const float *pair_E, *pair_c2e, *diag_c2e;  // constants of k_pair_gram_bm (HostTables)
   const int32_t *jn_start, *jn;               // neighbours of every joint (HostTables::jn)
+  // GENERAL path (more than 16 betas / more than 8 skinning weights per vertex, kernels_gen.inc)
+  int general;
+  const float* sdg;        // (Vp, 3, S) shapedirs, vertex-major
+  const int32_t* segall;   // (nsegall, 3) part-aligned tiles over every slot
+  int nsegall;
 };
 
 // One cell table on the device (sf::ShareTable) as the kernels take it, with the multiplier a launch picked.
@@ -234,6 +239,9 @@ struct Workspace {
   float* gramP;    // (workgroups of k_pair_gram_bm, NG, Mp) pair-Gram partial sums
   float* wT;       // (Mp/64, Vp, 64) vertex weights at the sorted slots (padding slots: 0), k_layout_weights
   float* accP;     // (cells, NE+1, Mp) cell records of the weighted accumulate (k_accum_w_bm)
+  // general path: the S-sized scratch of the per-instance stages lives here instead of LDS
+  float* gT;       // (B,J,3,S+1) T = P - G J_ext of the joint stage (its P is ws.pext)
+  float* gsolve;   // (B, solve_scratch_floats(S)) the S x S system of stage S
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -292,13 +300,15 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w, bool fwd_
   ws.mbj = (float*)take((size_t)B * J * 3 * 4);
   ws.scale = (float*)take((size_t)B * 4);
   ws.regref = (float*)take((size_t)B * S * 4, true);
-  ws.cen = (double*)take(((size_t)B + 1) * (S * S + S) * 8);
-  ws.cenP = (double*)take(((size_t)B + 63) / 64 * (S * S + S) * 8);
+  // (the general path has no share_beta solve: its (S^2 + S) rows per instance are not reserved)
+  ws.cen = (double*)take(t.general ? 0 : ((size_t)B + 1) * (S * S + S) * 8);
+  ws.cenP = (double*)take(t.general ? 0 : ((size_t)B + 63) / 64 * (S * S + S) * 8);
   ws.vextra = (float*)take((size_t)B * 32 * 4);
   ws.beta_out = (float*)take((size_t)B * S * 4);
   ws.tjs = (float*)take((size_t)B * J * 3 * 4);
-  ws.vpT = (float*)take(Mp * 3 * Vp * 4, true);
-  ws.tT = (float*)take(Mp * 3 * Vp * 4);
+  // (the batch-major streams: never read on the general path)
+  ws.vpT = (float*)take(t.general ? 0 : Mp * 3 * Vp * 4, true);
+  ws.tT = (float*)take(t.general ? 0 : Mp * 3 * Vp * 4);
   {
     // rows of partial sums: the coarse tables', and the fine tables' as well for a batch that may take them (whatever
     // SMPLFIT_FINE_B says at the time of the call)
@@ -324,7 +334,9 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w, bool fwd_
      // constants as the launch and the combine kernels)
     ws.gramP = (float*)take((size_t)pair_gram_workgroups((int)J, (int)t.pair_c3.size()) * sf::ne_ng((int)S) * Mp * 4);
   }
-  ws.jdT = (float*)take(Mp * align_up((size_t)J * sf::jd_stride(S), 64) * 4, true);
+  ws.jdT = (float*)take(t.general ? 0 : Mp * align_up((size_t)J * sf::jd_stride(S), 64) * 4, true);
+  ws.gT = (float*)take(t.general ? (size_t)B * J * 3 * (S + 1) * 4 : 0, true);
+  ws.gsolve = (float*)take(t.general ? (size_t)B * align_up((size_t)sf::solve_scratch_floats((int)S), 4) * 4 : 0);
   if (w) *w = ws;
   return off;
 }
@@ -356,6 +368,7 @@ __device__ __forceinline__ void st_stream(float* p, float v) {
 // the kernels (same anonymous namespace, same translation unit)
 #include "kernels_wave.inc"
 #include "kernels_bm.inc"
+#include "kernels_gen.inc"
 
 // ------------------------------------------------------------------------------------------------
 // launch helpers
@@ -669,6 +682,53 @@ void launch_center_sort(const DevModel& d, const float* tv, const float* tj, con
                      "unsupported (shape unknowns, skinning width) combination"); \
   } while (0)
 
+// GENERAL path (kernels_gen.inc): the vertex block of the normal equations and the LBS / part-sum pass with run-time
+// loops over the unknowns and the skinning weights
+void set_max_lds_once(const void* fn) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+int launch_gen_accum(const DevModel& d, const Workspace& ws, int B, bool weighted, hipStream_t st) {
+  const size_t lds = gen_accum_lds(d.S, d.KW);
+  if (lds > 160 * 1024) return fail(SMPLFIT_ERR_UNSUPPORTED, "general path: too many shape unknowns for the accumulate kernel's LDS tile");
+  static std::once_flag once[16];
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  std::call_once(once[dev_id & 15], [] {
+    set_max_lds_once(reinterpret_cast<const void*>(&k_gen_accum<true>));
+    set_max_lds_once(reinterpret_cast<const void*>(&k_gen_accum<false>));
+  });
+  if (weighted) hipLaunchKernelGGL(k_gen_accum<true>, dim3(B), dim3(kGenThreads), lds, st, d, ws, B);
+  else hipLaunchKernelGGL(k_gen_accum<false>, dim3(B), dim3(kGenThreads), lds, st, d, ws, B);
+  return 0;
+}
+template <int MODE>
+void launch_gen_lbs(const DevModel& d, const Workspace& ws, int B, bool weighted, int nb, const float* beta,
+                    const float* trans, float* out, hipStream_t st, const float* kid = nullptr) {
+  const size_t lds = gen_lbs_lds(d.J, d.S);
+  if (weighted && MODE != 2)
+    hipLaunchKernelGGL((k_gen_lbs<MODE == 2 ? 0 : MODE, true>), dim3(B), dim3(256), lds, st, d, ws, B, nb, beta, trans, kid, out);
+  else
+    hipLaunchKernelGGL((k_gen_lbs<MODE, false>), dim3(B), dim3(256), lds, st, d, ws, B, nb, beta, trans, kid, out);
+}
+// the vertex block / the LBS pass of the wave-per-instance path OR the general one, by model
+int launch_accum_any(const DevModel& d, const Workspace& ws, int B, bool weighted, hipStream_t st) {
+  if (d.general) return launch_gen_accum(d, ws, B, weighted, st);
+#define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, B, weighted, st)
+  SF_DISPATCH_SKW(d, SF_CALL_ACCUM);
+#undef SF_CALL_ACCUM
+  return 0;
+}
+template <int MODE>
+int launch_lbs_any(const DevModel& d, const Workspace& ws, int B, bool weighted, int nb, const float* beta,
+                   const float* trans, float* out, hipStream_t st, const float* kid = nullptr) {
+  if (d.general) {
+    launch_gen_lbs<MODE>(d, ws, B, weighted, nb, beta, trans, out, st, kid);
+    return 0;
+  }
+#define SF_CALL_LBS(S_, KW_) launch_lbs<S_, KW_, MODE, false>(d, ws, B, weighted, nb, beta, trans, out, 0.f, 0.f, st, kid)
+  SF_DISPATCH_SKW(d, SF_CALL_LBS);
+#undef SF_CALL_LBS
+  return 0;
+}
+
 size_t chunked_workspace_bytes(const sf::HostTables& t, int batch, const sf::HostTables* tin = nullptr);
 
 int check_common(const smplfit_handle* h, int batch, void* workspace, size_t workspace_bytes) {
@@ -778,10 +838,11 @@ int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, b
   return 0;
 }
 
+// (general path: the S-sized parts of the scratch — P, T, the S x S system — live in the workspace, see gen_joint_scratch)
 size_t joint_lds(const DevModel& d, int kind = 0) {
-  return (size_t)sf::joint_scratch_floats(d.J, d.S, kind) * 4;
+  return (size_t)sf::joint_scratch_floats(d.J, d.general ? 0 : d.S, kind) * 4;
 }
-size_t solve_lds(const DevModel& d) { return (size_t)sf::solve_scratch_floats(d.S) * 4; }
+size_t solve_lds(const DevModel& d) { return d.general ? 0 : (size_t)sf::solve_scratch_floats(d.S) * 4; }
 
 // The per-instance stages run two instances per wave (DevCtxHalf) when the model's joints fit 32 lanes and the batch
 // fills the chip either way (below ~2 workgroups per CU the one-instance form is the faster one: B = 256 0.416 vs
@@ -792,7 +853,7 @@ size_t solve_lds(const DevModel& d) { return (size_t)sf::solve_scratch_floats(d.
 #define SMPLFIT_STAGE_HALF 7
 #endif
 inline bool stage_half(const DevModel& d, int bit, int B) {
-  return (SMPLFIT_STAGE_HALF & bit) && d.J <= 32 && B >= tune().stage_half_b;
+  return (SMPLFIT_STAGE_HALF & bit) && d.J <= 32 && B >= tune().stage_half_b && !d.general;
 }
 
 void launch_joint_stage(const DevModel& d, JointStageArgs ja, const Workspace& ws, int B, hipStream_t st) {
@@ -880,6 +941,9 @@ int launch_convert_source(const ConvertSource& src, const DevModel& d_out, const
 int enqueue_solve(const DevModel& d, const Workspace& ws, int B, const FitOptions& o, bool joints, bool eff_v,
                   bool eff_j, const float* jw, int pair_in, int use_ref, bool scaled, hipStream_t st,
                   bool extras_done = false) {
+  if (d.general && (scaled || o.share_beta))
+    return fail(SMPLFIT_ERR_UNSUPPORTED, "models on the general path (more than 16 betas or more than 8 skinning weights per "
+                                         "vertex): scale_target / scale_fit / share_beta are not implemented");
   if (scaled) {
     // (extras_done: the batch-major accumulate of this iteration has left the extra sums in ws.vextra)
 #define SF_CALL_EXTRAS(S_, KW_)                                                                       \
@@ -974,7 +1038,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   ja.jw = jw;
   ja.joint_block = joints ? 1 : 0;
   ja.joint_block_weighted = eff_j ? 1 : 0;
-  ja.vertex_sa_closed_form = eff_v ? 0 : 1;
+  ja.vertex_sa_closed_form = (eff_v || d.general) ? 0 : 1;  // (the general accumulate sums SA itself)
   ja.do_prologue = o.rotations_only ? 0 : 1;
   ja.fit_rotations = 1;
   ja.Gprev = nullptr;
@@ -1003,10 +1067,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     } else if (on(0)) {
       hipLaunchKernelGGL(k_forward_joint, dim3(B), dim3(64), joint_lds(d), st, d, fa, ws);
       launch_gemm(d, ws, B, st);
-#define SF_CALL_LBS(S_, KW_) \
-  launch_lbs<S_, KW_, 1, false>(d, ws, B, vweighted, d.S, ws.beta, ws.trans, nullptr, 0.f, 0.f, st)
-      SF_DISPATCH_SKW(d, SF_CALL_LBS);
-#undef SF_CALL_LBS
+      if (int rc = launch_lbs_any<1>(d, ws, B, vweighted, d.S, ws.beta, ws.trans, nullptr, st)) return rc;
       if (!joints)
         hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(64), 0, st, d, ws.rverts, ws.rjreg);
     }
@@ -1045,16 +1106,14 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
       else launch_residual_bm(h, ws, B, st);
     } else {
       launch_gemm(d, ws, B, st);
-#define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, B, eff_v, st)
-      SF_DISPATCH_SKW(d, SF_CALL_ACCUM);
-#undef SF_CALL_ACCUM
+      if (int rc = launch_accum_any(d, ws, B, eff_v, st)) return rc;
     }
     // K4 stays its own launch: fused into the prologue of the LBS kernel (template flag SOLVE) its
     // ~40 serial barriers stall all four waves of the workgroup and the kernel ran 230 us longer
     const bool scaled_now = o.scale_mode && it + 1 == o.num_iter;  // only the last solve (:434-455)
     // (the accumulate kernel — weighted fits, and the scaled iteration on the batch-major path — leaves the complete
     // record: the classic form of the solve; the residual pass the pair-Gram form)
-    const int pair_in = (!eff_v && !(bm && scaled_now) && (bm || use_pair_form())) ? 1 : 0;
+    const int pair_in = (!eff_v && !d.general && !(bm && scaled_now) && (bm || use_pair_form())) ? 1 : 0;
     if (pb)
       if (int rc = enqueue_solve(d, ws, B, o, joints, eff_v, eff_j, jw, pair_in, use_ref, scaled_now, st, bm && scaled_now))
         return rc;
@@ -1066,15 +1125,9 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
       SF_DISPATCH_SKW(d, SF_CALL_LBS);
 #undef SF_CALL_LBS
     } else if (joints) {
-#define SF_CALL_LBS(S_, KW_) \
-  launch_lbs<S_, KW_, 0, false>(d, ws, B, vweighted, d.S, ws.beta, ws.trans, nullptr, 0.f, 0.f, st)
-      SF_DISPATCH_SKW(d, SF_CALL_LBS);
-#undef SF_CALL_LBS
+      if (int rc = launch_lbs_any<0>(d, ws, B, vweighted, d.S, ws.beta, ws.trans, nullptr, st)) return rc;
     } else {
-#define SF_CALL_LBS(S_, KW_) \
-  launch_lbs<S_, KW_, 1, false>(d, ws, B, vweighted, d.S, ws.beta, ws.trans, nullptr, 0.f, 0.f, st)
-      SF_DISPATCH_SKW(d, SF_CALL_LBS);
-#undef SF_CALL_LBS
+      if (int rc = launch_lbs_any<1>(d, ws, B, vweighted, d.S, ws.beta, ws.trans, nullptr, st)) return rc;
       hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(64), 0, st, d, ws.rverts, ws.rjreg);
     }
     if (last) break;
@@ -1175,10 +1228,7 @@ int run_fit_known_shape(const smplfit_handle* h, const float* betas, int nb, con
     } else {
       launch_gemm(d, ws, B, st);
       // MODE 1: the posed mesh is kept (regressed joints, alignment sums) next to the part sums
-#define SF_CALL_LBS(S_, KW_) \
-  launch_lbs<S_, KW_, 1, false>(d, ws, B, vweighted, d.S, ws.beta, ws.trans, nullptr, 0.f, 0.f, st)
-      SF_DISPATCH_SKW(d, SF_CALL_LBS);
-#undef SF_CALL_LBS
+      if (int rc = launch_lbs_any<1>(d, ws, B, vweighted, d.S, ws.beta, ws.trans, nullptr, st)) return rc;
       if (!joints)
         hipLaunchKernelGGL(k_regress_joints, dim3(B), dim3(64), 0, st, d, ws.rverts, ws.rjreg);
     }
@@ -1491,7 +1541,7 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
     delete h;
     return fail(unsupported ? SMPLFIT_ERR_UNSUPPORTED : SMPLFIT_ERR_BAD_ARG, err);
   }
-  if (h->t.S + 3 > 3 * h->t.J) {
+  if (!h->t.general && h->t.S + 3 > 3 * h->t.J) {
     delete h;
     return fail(SMPLFIT_ERR_UNSUPPORTED, "smplfit_create: num_betas too large for this joint count");
   }
@@ -1520,6 +1570,18 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
   auto up = [&](auto& vec, auto** dst) {
     if (rc == 0) rc = upload(h, vec, dst);
   };
+  d.general = t.general ? 1 : 0;
+  {
+    std::vector<int32_t> sa;
+    for (auto& sg : t.segments_all) {
+      sa.push_back(sg.start);
+      sa.push_back(sg.count);
+      sa.push_back(sg.part);
+    }
+    d.nsegall = (int)t.segments_all.size();
+    up(sa, &d.segall);
+  }
+  up(t.sdg, &d.sdg);
   up(t.perm, &d.perm);
   up(seg, &d.segments);
   std::vector<int32_t> pss(t.J + 1, 0);
@@ -1708,7 +1770,7 @@ int smplfit_get_info(const smplfit_handle* h, smplfit_info* info) {
   info->adj_last_level = t.adj_last_level;
   info->has_device = h->has_device ? 1 : 0;
   info->gemm_vgprs = h->gemm_vgprs;
-  info->vertex_path = bm_applies(h) ? SMPLFIT_PATH_BATCH_MAJOR : SMPLFIT_PATH_WAVE;
+  info->vertex_path = t.general ? SMPLFIT_PATH_GENERAL : bm_applies(h) ? SMPLFIT_PATH_BATCH_MAJOR : SMPLFIT_PATH_WAVE;
   info->share_fallback = t.share_fallback;
   return SMPLFIT_OK;
 }
@@ -1924,10 +1986,7 @@ int smplfit_forward_ex_f32(const smplfit_handle* h, const smplfit_forward_args* 
                        ws.vpT, vertices, batch);
   } else if (vertices) {
     launch_gemm(d, ws, batch, st);
-#define SF_CALL_LBS(S_, KW_) \
-  launch_lbs<S_, KW_, 2, false>(d, ws, batch, false, fa.nb, shape_betas, trans, vertices, 0.f, 0.f, st, kid_factor)
-    SF_DISPATCH_SKW(d, SF_CALL_LBS);
-#undef SF_CALL_LBS
+    if (int rc = launch_lbs_any<2>(d, ws, batch, false, fa.nb, shape_betas, trans, vertices, st, kid_factor)) return rc;
   }
   return post_launch_check();
 }
@@ -2017,7 +2076,7 @@ int smplfit_shape_solve_ex_f32(const smplfit_handle* h, const smplfit_shape_solv
   ja.do_prologue = 1;
   ja.joint_block = joints ? 1 : 0;
   ja.joint_block_weighted = eff_j ? 1 : 0;
-  ja.vertex_sa_closed_form = eff_v ? 0 : 1;
+  ja.vertex_sa_closed_form = (eff_v || d.general) ? 0 : 1;  // (the general accumulate sums SA itself)
   if (!joints) hipMemsetAsync(ws.tjreg, 0, (size_t)batch * d.J * 3 * 4, st);
   launch_joint_stage(d, ja, ws, batch, st);
   if (bm) {
@@ -2030,10 +2089,8 @@ int smplfit_shape_solve_ex_f32(const smplfit_handle* h, const smplfit_shape_solv
                        scaled);
   } else {
     launch_gemm(d, ws, batch, st);
-#define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, batch, eff_v, st)
-    SF_DISPATCH_SKW(d, SF_CALL_ACCUM);
-#undef SF_CALL_ACCUM
-    rc = enqueue_solve(d, ws, batch, o, joints, eff_v, eff_j, joint_weights, (!eff_v && use_pair_form()) ? 1 : 0,
+    if (int rc = launch_accum_any(d, ws, batch, eff_v, st)) return rc;
+    rc = enqueue_solve(d, ws, batch, o, joints, eff_v, eff_j, joint_weights, (!eff_v && !d.general && use_pair_form()) ? 1 : 0,
                        use_ref, scaled, st);
   }
   if (rc) return rc;
@@ -2055,10 +2112,7 @@ int smplfit_shape_solve_ex_f32(const smplfit_handle* h, const smplfit_shape_solv
                        ws.vpT, args->vertices_out, batch);
   } else if (args->vertices_out) {
     float* vertices_out = args->vertices_out;
-#define SF_CALL_LBS(S_, KW_) \
-  launch_lbs<S_, KW_, 2, false>(d, ws, batch, false, d.S, ws.beta, ws.trans, vertices_out, 0.f, 0.f, st)
-    SF_DISPATCH_SKW(d, SF_CALL_LBS);
-#undef SF_CALL_LBS
+    if (int rc = launch_lbs_any<2>(d, ws, batch, false, d.S, ws.beta, ws.trans, vertices_out, st)) return rc;
   }
   return post_launch_check();
 }
@@ -2267,9 +2321,7 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
           launch_residual_bm(h, ws, batch, st, 1);
           return 0;
         }
-#define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, batch, false, st)
-        SF_DISPATCH_SKW(d, SF_CALL_ACCUM);
-#undef SF_CALL_ACCUM
+        if (int rc = launch_accum_any(d, ws, batch, false, st)) return rc;
         return 0;
       }
       case SMPLFIT_KERNEL_SHAPE_SOLVE:
@@ -2281,10 +2333,7 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
           else launch_lbs_bm<10, 4>(h, ws, batch, st);
           return 0;
         }
-#define SF_CALL_LBS(S_, KW_) \
-  launch_lbs<S_, KW_, 0, false>(d, ws, batch, false, d.S, ws.beta, ws.trans, nullptr, 0.f, 0.f, st)
-        SF_DISPATCH_SKW(d, SF_CALL_LBS);
-#undef SF_CALL_LBS
+        if (int rc = launch_lbs_any<0>(d, ws, batch, false, d.S, ws.beta, ws.trans, nullptr, st)) return rc;
         return 0;
       }
       default: return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_time_kernel_f32: unknown kernel id");
@@ -2300,9 +2349,7 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
     if (kernel_id == SMPLFIT_KERNEL_LBS_PARTSUM && bm)
       launch_shape_solve(d, ws, batch, st, 1.0f, 0.0f, 1.0f, 1, 0);
     if (kernel_id == SMPLFIT_KERNEL_LBS_PARTSUM && !bm) {
-#define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, batch, false, st)
-      SF_DISPATCH_SKW(d, SF_CALL_ACCUM);
-#undef SF_CALL_ACCUM
+      if (int rc = launch_accum_any(d, ws, batch, false, st)) return rc;
     }
     return 0;
   };

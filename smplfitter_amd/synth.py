@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import hashlib
 import os
+import re
 import os.path as osp
 import pickle
 
@@ -130,15 +131,17 @@ def make_model_arrays(kind='smpl', seed=0, num_vertices=None, num_betas=10, shuf
     bone parts' twist about the bone axis is recovered from the vertices' off-axis spread
     (pt/bodyfitter.py:1398-1410), so thin parts make pose_rotvecs ill-conditioned in the reference itself;
     on the fat variant a tight pose_rotvecs comparison is meaningful."""
-    if kind.endswith('_b16'):  # the same construction with 16 shape directions ('smpl_b16')
-        kind, num_betas = kind[:-4], 16
+    m = re.search(r'_b(\d+)$', kind)
+    if m:  # the same construction with that many shape directions ('smpl_b16'; 'smpl_b32', 'smpl_b300': the general path)
+        kind, num_betas = kind[:m.start()], int(m.group(1))
     # skinning variants: '_w6' keeps the SIX largest weights of a vertex (real models are not capped at four: the
     # reference blends with the dense (V, J) matrix, pt/bodyfitter.py:1000-1003); '_rnd' gives every vertex its own
     # part (weight 0.75) and THREE RANDOM other joints — joint sets the distance-based construction never produces
     # (the vertex-piece / cell tables of the batch-major kernels must cope with any of them)
     skin_nnz, skin_random = 4, False
-    if kind.endswith('_w6'):
-        kind, skin_nnz = kind[:-3], 6
+    m = re.search(r'_w(\d+)$', kind)
+    if m:  # ('_w6': eight pairs per vertex; '_w12': more than eight — the general path)
+        kind, skin_nnz = kind[:m.start()], int(m.group(1))
     if kind.endswith('_rnd'):
         kind, skin_random = kind[:-4], True
     fat = kind.endswith('_fat')

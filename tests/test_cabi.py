@@ -104,6 +104,31 @@ def test_host_tables_match_reference_structure(lib, name, model_root, golden):
     h.close()
 
 
+@pytest.mark.parametrize('kind', list(util.GENERAL_KINDS))
+def test_general_models_create(lib, kind, model_root):
+    """More than 16 betas / more than 8 skinning weights per vertex: the handle is created (rounds 1-4 refused these at
+    smplfit_create), reports the general path, the caller's own num_betas, and the part tables of the reference."""
+    import hostemu_util as H
+
+    md = util.load_general_md(model_root, kind)
+    desc, keep = H.desc_from_md(md, 'smpl')
+    h = _lib.Handle(desc, host_only=True)
+    _, of = util.make_oracle(md, 'smpl')
+    assert h.info.vertex_path == _lib.SMPLFIT_PATH_GENERAL
+    assert h.info.num_betas == md.shapedirs.shape[2] and h.info.has_kid == 0
+    assert h.info.skin_width == (12 if kind == 'smpl_w12' else 4)
+    assert (h.table('part_assignment') == of.part).all()
+    assert len(h.table('vertex_pieces')) == 0 and len(h.table('cell_counts')) == 0 and len(h.table('joint_pairs')) == 0
+    perm = h.table('sort_perm')
+    assert sorted(perm[perm >= 0].tolist()) == list(range(md.num_vertices))
+    assert h.workspace_bytes(8) > 0
+    h.close()
+    desc, keep = H.desc_from_md(md, 'smpl', enable_kid=True)
+    hk = _lib.Handle(desc, host_only=True)
+    assert hk.info.has_kid == 1 and hk.info.num_betas == md.shapedirs.shape[2]
+    hk.close()
+
+
 def check_share_tables(h, of, md, perm, V, plain=True):
     """Every cell table deals its domain (all slots / used parts / adjustable parts) exactly once to its cells, in
     cells of nearly equal cost, and its rows say where the partial sums go."""

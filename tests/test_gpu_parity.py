@@ -75,6 +75,60 @@ def test_forward_goldens(name, path, model_root, golden, dev, smplfit_env):
     assert 'vertices' not in j and np.abs(j['joints'] - g['fwd_joints']).max() < 2e-6
 
 
+@pytest.mark.parametrize('kind', list(util.GENERAL_KINDS))
+def test_general_goldens(kind, model_root, golden, dev):
+    """Models of the GENERAL path (smplfit_info.vertex_path == 2): 32 betas, num_betas=None on a 300-column file (the
+    reference's _fit_shape_general, pt/bodyfitter.py:202, 1104-1319), twelve skinning weights per vertex — forward, the
+    fits of golden_general.npz and the conversion BodyConverter runs, against the reference's outputs."""
+    from smplfitter_amd import _lib
+    from smplfitter_amd.pt import BodyConverter, BodyFitter, BodyModel
+
+    gg = golden('general')
+    nb = util.GENERAL_KINDS[kind]
+    m = BodyModel('smpl', 'neutral', model_root=f'{model_root}/{kind}', num_betas=nb, device=dev)
+    assert m.num_betas == int(gg[f'{kind}.num_betas'])
+    info = m._native(dev).info
+    assert info.vertex_path == _lib.SMPLFIT_PATH_GENERAL and info.num_betas == m.num_betas
+    md = util.load_general_md(model_root, kind)
+    om64 = util.O.OracleModel(md, np.float64, 'smpl')
+    pre = kind + '.'
+    fw = to_np(m(t(gg[pre + 'pose'], dev), t(gg[pre + 'betas'], dev), t(gg[pre + 'trans'], dev)))
+    assert np.abs(fw['vertices'] - gg[pre + 'target_vertices']).max() < 3e-6
+    assert np.abs(fw['joints'] - gg[pre + 'target_joints']).max() < 3e-6
+    assert np.abs(fw['orientations'] - gg[pre + 'fwd_orientations']).max() < 1e-6
+    if pre + 'fwd10_joints' in gg:  # fewer betas given than the model has (the README's conversion example)
+        fw10 = to_np(m(t(gg[pre + 'pose'], dev), t(gg[pre + 'betas'][:, :10], dev), t(gg[pre + 'trans'], dev)))
+        assert np.abs(fw10['vertices'][:, ::50] - gg[pre + 'fwd10_vertices_every_50th']).max() < 3e-6
+        assert np.abs(fw10['joints'] - gg[pre + 'fwd10_joints']).max() < 3e-6
+    fitters = {False: BodyFitter(m), True: BodyFitter(m, enable_kid=True)}
+    for case, c in util.GENERAL_CASES.items():
+        tv, kw = util.general_fit_args(gg, kind, case)
+        kw = {k: (t(v, dev) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+        keys = ['pose_rotvecs', 'shape_betas', 'trans'] + (['kid_factor'] if c.get('kid') else [])
+        o = to_np(fitters[c.get('kid', False)].fit(t(tv, dev), requested_keys=keys, **kw))
+        util.check_general(om64, gg, kind, case, o)
+        ref = gg[f'{kind}.fit.{case}.pose_rotvecs']
+        assert np.abs(o['pose_rotvecs'] - ref).max() < 1e-3, (kind, case)
+    # the reference's quick-start conversion (README.md:105-116): both models built without num_betas; same topology here
+    conv = BodyConverter(m, m)
+    o = to_np(conv.convert(t(gg[pre + 'pose'], dev), t(gg[pre + 'betas'], dev), t(gg[pre + 'trans'], dev)))
+    ref = {k: gg[f'{kind}.fit.conv.{k}'] for k in ('pose_rotvecs', 'shape_betas', 'trans')}
+    va = om64.forward(o['pose_rotvecs'], o['shape_betas'], o['trans'])['vertices']
+    vb = om64.forward(ref['pose_rotvecs'], ref['shape_betas'], ref['trans'])['vertices']
+    assert np.linalg.norm(va - vb, axis=-1).max() < 1e-4
+    # options the general path does not implement raise (never a silently different result)
+    with pytest.raises(NotImplementedError):
+        fitters[False].fit(t(gg[pre + 'target_vertices'], dev), t(gg[pre + 'target_joints'], dev), share_beta=True)
+    with pytest.raises(NotImplementedError):
+        fitters[False].fit(t(gg[pre + 'target_vertices'], dev), t(gg[pre + 'target_joints'], dev), scale_target=True)
+    # run to run: bit-identical
+    tv, kw = util.general_fit_args(gg, kind, 'it3_reg1_j_nw_fa')
+    kw = {k: (t(v, dev) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+    a = to_np(fitters[False].fit(t(tv, dev), **kw))
+    b = to_np(fitters[False].fit(t(tv, dev), **kw))
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+
+
 @pytest.fixture(params=['batch-major', 'wave-per-instance'])
 def vertex_path(request, smplfit_env):
     """The default fit takes the batch-major vertex kernels where they apply (unit vertex weights, joints

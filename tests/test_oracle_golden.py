@@ -303,6 +303,31 @@ def test_num_betas_goldens(nb, model_root, golden):
         util.check_nb(om64, gnb, nb, kid, cfg, o)
 
 
+@pytest.mark.parametrize('kind', list(util.GENERAL_KINDS))
+def test_general_goldens(kind, model_root, golden):
+    """The oracle against the reference's fixture for the models of the library's general path: 32 betas, every column
+    of a 300-column file (num_betas=None; the reference's _fit_shape_general), twelve skinning weights per vertex
+    (golden_general.npz, tests/golden/make_golden_general.py)."""
+    from smplfitter_amd import synth
+
+    gg = golden('general')
+    md = util.load_general_md(model_root, kind)
+    assert synth.model_sha256(synth.make_model_arrays(kind, seed=0)) == str(gg[f'{kind}.model_sha256'])
+    assert md.shapedirs.shape[2] == int(gg[f'{kind}.num_betas'])
+    assert (md.weights != 0).sum(1).max() == int(gg[f'{kind}.skin_nnz'])
+    om64, om = O.OracleModel(md, np.float64, 'smpl'), O.OracleModel(md, np.float32, 'smpl')
+    fw = om.forward(gg[f'{kind}.pose'], gg[f'{kind}.betas'], gg[f'{kind}.trans'])
+    assert np.abs(fw['vertices'] - gg[f'{kind}.target_vertices']).max() < 3e-6
+    assert np.abs(fw['joints'] - gg[f'{kind}.target_joints']).max() < 3e-6
+    if f'{kind}.fwd10_joints' in gg:  # fewer betas given than the model has
+        fw10 = om.forward(gg[f'{kind}.pose'], gg[f'{kind}.betas'][:, :10], gg[f'{kind}.trans'])
+        assert np.abs(fw10['vertices'][:, ::50] - gg[f'{kind}.fwd10_vertices_every_50th']).max() < 3e-6
+    for case, c in util.GENERAL_CASES.items():
+        tv, kw = util.general_fit_args(gg, kind, case)
+        o = O.OracleFitter(om, enable_kid=c.get('kid', False)).fit(tv, **kw)
+        util.check_general(om64, gg, kind, case, o)
+
+
 @pytest.mark.parametrize('tag', ['s2x', 'x2s'])
 def test_convert_cross_topology_goldens(tag, model_root, golden, data_root_fat):
     """BodyConverter between the two topologies (reference pt/bodyconverter.py:22-149 run on the synthetic

@@ -44,6 +44,52 @@ def check_nb(om64, gnb, nb, kid, cfg, o):
     assert np.abs(o['shape_betas'] - ref['shape_betas']).max() < 2e-3, (nb, kid, cfg)
 
 
+# models of the library's GENERAL path (tests/golden/make_golden_general.py): kind -> num_betas (None: every column)
+GENERAL_KINDS = {'smpl_b32': 32, 'smpl_b300': None, 'smpl_w12': 10}
+GENERAL_CASES = {
+    'it3_reg1_j_nw_fa': dict(joints=True, weights=False, kw=dict(num_iter=3, beta_regularizer=1.0)),
+    'it2_reg0_nj_nw_nfa': dict(joints=False, weights=False, kw=dict(num_iter=2, beta_regularizer=0.0, final_adjust_rots=False)),
+    'it2_reg1_j_w_fa': dict(joints=True, weights=True, kw=dict(num_iter=2, beta_regularizer=1.0)),
+    # what BodyConverter.convert runs (pt/bodyconverter.py:74-88): enable_kid fitter
+    'conv': dict(joints=False, weights=False, kid=True,
+                 kw=dict(num_iter=1, beta_regularizer=0.0, final_adjust_rots=False, kid_regularizer=1e9)),
+}
+
+
+def load_general_md(root, kind):
+    return modelio.load_model('smpl', 'neutral', model_root=f'{root}/{kind}', num_betas=GENERAL_KINDS[kind])
+
+
+def general_fit_args(gg, kind, case):
+    """(target_vertices, keyword arguments) of a fixture case, as numpy arrays."""
+    c = GENERAL_CASES[case]
+    pre = kind + '.'
+    kw = dict(c['kw'])
+    kw['target_joints'] = gg[pre + 'target_joints'] if c['joints'] else None
+    if c['weights']:
+        kw['vertex_weights'] = gg[pre + 'vertex_weights']
+        kw['joint_weights'] = gg[pre + 'joint_weights']
+    return gg[pre + 'target_vertices'], kw
+
+
+def check_general(om64, gg, kind, case, o, mesh_tol=1e-4):
+    """A fit of a general-path model against the reference's fixture: the mesh gate of every other fixture."""
+    pre = f'{kind}.fit.{case}.'
+    kid = GENERAL_CASES[case].get('kid', False)
+    ref = {k: gg[pre + k] for k in ('pose_rotvecs', 'shape_betas', 'trans') + (('kid_factor',) if kid else ())}
+    assert o['shape_betas'].shape == ref['shape_betas'].shape
+    kw_o = dict(kid_factor=np.asarray(o['kid_factor'])) if kid else {}
+    kw_r = dict(kid_factor=ref['kid_factor']) if kid else {}
+    va = om64.forward(np.asarray(o['pose_rotvecs']), np.asarray(o['shape_betas']), np.asarray(o['trans']), **kw_o)['vertices']
+    vb = om64.forward(ref['pose_rotvecs'], ref['shape_betas'], ref['trans'], **kw_r)['vertices']
+    err = np.linalg.norm(va - vb, axis=-1).max()
+    db, dt = np.abs(o['shape_betas'] - ref['shape_betas']).max(), np.abs(o['trans'] - ref['trans']).max()
+    print(f'[general] {kind:10s} {case:20s} vtx {err:.2e} betas {db:.2e} trans {dt:.2e}')
+    assert err < mesh_tol, (kind, case, err)
+    assert dt < 5e-5, (kind, case, dt)
+    return err
+
+
 def model_dir(name):
     """Directory of golden set ``name`` under the synthetic model root (smplxfat: the fat-part SMPL-X
     variant of synth.make_model_arrays('smplx_fat'), its own directory, the official SMPL-X file name; the
