@@ -414,6 +414,15 @@ enum smplfit_kernel_id {
                                        layout in one pass (k_layout_targets)                        */
   SMPLFIT_KERNEL_TEMPLATE_PARTSUM = 8, /* batch-major path: part sums against the template (first
                                        rotation estimate, k_template_partsum_bm)                    */
+  /* the remaining launches of a default fit, so that a caller can attribute the whole step (bench.py's
+   * roofline.kernel_ms / fit_breakdown): */
+  SMPLFIT_KERNEL_JOINT_STAGE = 9,   /* K1 part rotations + shape prologue (k_joint_stage)            */
+  SMPLFIT_KERNEL_REFINE = 10,       /* K6 dependent refinement + epilogue (k_refine_epilogue)       */
+  SMPLFIT_KERNEL_GRAM_COMBINE = 11, /* batch-major path: partial sums -> normal-equation record     */
+  SMPLFIT_KERNEL_PSUM_COMBINE = 12, /* batch-major path: rows of part sums -> (B, J, 16)            */
+  SMPLFIT_KERNEL_JD_TRANSPOSE = 13, /* batch-major path: joint rows instance-innermost              */
+  SMPLFIT_KERNEL_MEAN_FINISH = 14,  /* batch-major path: mean of the targets, centred joints        */
+  SMPLFIT_KERNEL_LBS_LAST = 15,     /* batch-major path: the last LBS / part-sum pass (adjustable parts only) + combine */
 };
 int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, int reps,
                             void* workspace, size_t workspace_bytes, void* hip_stream,

@@ -692,11 +692,19 @@ int launch_gen_accum(const DevModel& d, const Workspace& ws, int B, bool weighte
   int dev_id = 0;
   (void)hipGetDevice(&dev_id);
   std::call_once(once[dev_id & 15], [] {
-    set_max_lds_once(reinterpret_cast<const void*>(&k_gen_accum<true>));
-    set_max_lds_once(reinterpret_cast<const void*>(&k_gen_accum<false>));
+    set_max_lds_once(reinterpret_cast<const void*>(&k_gen_accum<true, 8, 256>));
+    set_max_lds_once(reinterpret_cast<const void*>(&k_gen_accum<false, 8, 256>));
+    set_max_lds_once(reinterpret_cast<const void*>(&k_gen_accum<true, 32, 256>));
+    set_max_lds_once(reinterpret_cast<const void*>(&k_gen_accum<false, 32, 256>));
   });
-  if (weighted) hipLaunchKernelGGL(k_gen_accum<true>, dim3(B), dim3(kGenThreads), lds, st, d, ws, B);
-  else hipLaunchKernelGGL(k_gen_accum<false>, dim3(B), dim3(kGenThreads), lds, st, d, ws, B);
+  const bool wide = gen_tile_vertices(d.S) == 32, one_wave = gen_accum_threads(d.S) == 64;
+  if (one_wave) {  // (few unknowns: a wave per instance, 32 vertices per tile, LDS < 64 KB)
+    if (weighted) hipLaunchKernelGGL((k_gen_accum<true, 32, 64>), dim3(B), dim3(64), lds, st, d, ws, B);
+    else hipLaunchKernelGGL((k_gen_accum<false, 32, 64>), dim3(B), dim3(64), lds, st, d, ws, B);
+  } else if (weighted && wide) hipLaunchKernelGGL((k_gen_accum<true, 32, 256>), dim3(B), dim3(256), lds, st, d, ws, B);
+  else if (weighted) hipLaunchKernelGGL((k_gen_accum<true, 8, 256>), dim3(B), dim3(256), lds, st, d, ws, B);
+  else if (wide) hipLaunchKernelGGL((k_gen_accum<false, 32, 256>), dim3(B), dim3(256), lds, st, d, ws, B);
+  else hipLaunchKernelGGL((k_gen_accum<false, 8, 256>), dim3(B), dim3(256), lds, st, d, ws, B);
   return 0;
 }
 template <int MODE>
@@ -2336,6 +2344,61 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
         if (int rc = launch_lbs_any<0>(d, ws, batch, false, d.S, ws.beta, ws.trans, nullptr, st)) return rc;
         return 0;
       }
+      case SMPLFIT_KERNEL_JOINT_STAGE: {  // a rotation pass + prologue on the state of the last fit
+        JointStageArgs ja{};
+        ja.tj = ws.tjc;
+        ja.rj = ws.rjoints;
+        ja.rj_shared = 0;
+        ja.Gprev = ws.G;
+        ja.jw = nullptr;
+        ja.fit_rotations = 1;
+        ja.do_prologue = 1;
+        ja.joint_block = 1;
+        ja.joint_block_weighted = 0;
+        ja.vertex_sa_closed_form = d.general ? 0 : 1;
+        launch_joint_stage(d, ja, ws, batch, st);
+        return 0;
+      }
+      case SMPLFIT_KERNEL_REFINE: {  // (outputs into the workspace: ws.tvs is unused between fits)
+        RefineArgs ra{};
+        ra.tj = ws.tjc;
+        ra.rj_term = ws.rjoints;
+        ra.jw = nullptr;
+        ra.final_adjust = 1;
+        float* scratch = bm ? ws.tvs : ws.rverts;
+        ra.pose = scratch;
+        ra.betas = scratch + (size_t)batch * d.J * 3;
+        ra.trans = ra.betas + (size_t)batch * d.S;
+        ra.kid = nullptr;
+        ra.orient = ra.trans + (size_t)batch * 3;  // (a fit always writes the orientations and the relative rotations)
+        ra.rel = ra.orient + (size_t)batch * d.J * 9;
+        launch_refine(d, ra, ws, batch, st);
+        return 0;
+      }
+      case SMPLFIT_KERNEL_GRAM_COMBINE:
+        if (!bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "normal-equation combine: batch-major path not active");
+        launch_residual_bm(h, ws, batch, st, 4);
+        return 0;
+      case SMPLFIT_KERNEL_PSUM_COMBINE:
+        if (!bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "part-sum combine: batch-major path not active");
+        launch_psum_combine(d, share_view(h, sf::kShareLbsUsed, batch), ws, batch, Mp, st);
+        return 0;
+      case SMPLFIT_KERNEL_JD_TRANSPOSE:
+        if (!bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "joint-row transpose: batch-major path not active");
+        launch_jd_transpose(d, ws, batch, st);
+        return 0;
+      case SMPLFIT_KERNEL_MEAN_FINISH:
+        if (!bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "mean pass: batch-major path not active");
+        // (the slab sums of the layout pass are gone from ws.resP by now: the values are arbitrary, the work is the same;
+        // the outputs go where the fit left them)
+        hipLaunchKernelGGL(k_mean_finish, dim3(Mp / 64), dim3(64 * kMeanWaves), 0, st, d, ws.rjoints, ws.resP, ws, batch, Mp,
+                           (d.V + kSlabV - 1) / kSlabV);
+        return 0;
+      case SMPLFIT_KERNEL_LBS_LAST:
+        if (!bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "last LBS pass: batch-major path not active");
+        if (d.S == 11) launch_lbs_bm<11, 4>(h, ws, batch, st, false, true);
+        else launch_lbs_bm<10, 4>(h, ws, batch, st, false, true);
+        return 0;
       default: return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_time_kernel_f32: unknown kernel id");
     }
   };
@@ -2346,7 +2409,7 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
   auto pre = [&]() {
     if (nopre) return 0;
     if (kernel_id == SMPLFIT_KERNEL_SHAPE_ACCUM) launch_gemm(d, ws, batch, st, bm);
-    if (kernel_id == SMPLFIT_KERNEL_LBS_PARTSUM && bm)
+    if ((kernel_id == SMPLFIT_KERNEL_LBS_PARTSUM || kernel_id == SMPLFIT_KERNEL_LBS_LAST) && bm)
       launch_shape_solve(d, ws, batch, st, 1.0f, 0.0f, 1.0f, 1, 0);
     if (kernel_id == SMPLFIT_KERNEL_LBS_PARTSUM && !bm) {
       if (int rc = launch_accum_any(d, ws, batch, false, st)) return rc;

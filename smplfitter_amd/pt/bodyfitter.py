@@ -59,6 +59,7 @@ class BodyFitter(nn.Module):
         self.body_model = body_model
         self.n_betas = body_model.shapedirs.shape[2]
         self.enable_kid = enable_kid
+        self._torchfit = None  # tables of the differentiable restatement (pt/_autograd.py), built on first use
         self.is_smpl_family = body_model.model_name.startswith('smpl')
 
     def fit(
@@ -107,7 +108,18 @@ class BodyFitter(nn.Module):
                 'initial_kid_factor needs BodyFitter(enable_kid=True) on the HIP path')
         # the reference defaults the kid ridge weight to beta_regularizer (pt/bodyfitter.py:1235-1237)
         kid_reg = float(beta_regularizer if kid_regularizer is None else kid_regularizer)
-        if torch.compiler.is_compiling():  # one opaque operator for torch.compile / export
+        if torch.is_grad_enabled() and not torch.compiler.is_compiling() and any(
+                t is not None and t.requires_grad for t in (target_vertices, target_joints, vertex_weights, joint_weights)):
+            # gradients with respect to the targets / weights (reference: tests/pt/test_fitter_grad.py): the HIP kernels
+            # have no backward pass, so THIS call — and only a call whose inputs require gradients — runs the algorithm
+            # written with PyTorch operators (pt/_autograd.py) on the model's cuda device
+            result = self._fit_differentiable(
+                target_vertices, target_joints, vertex_weights, joint_weights, num_iter, beta_regularizer,
+                beta_regularizer2, kid_regularizer, final_adjust_rots,
+                unsupported=dict(share_beta=share_beta, scale_target=scale_target, scale_fit=scale_fit,
+                                 initial_pose_rotvecs=initial_pose_rotvecs, initial_shape_betas=initial_shape_betas,
+                                 initial_kid_factor=initial_kid_factor))
+        elif torch.compiler.is_compiling():  # one opaque operator for torch.compile / export
             pose, betas, trans, kid, orient, rel, scale = torch.ops.smplfitter_amd.fit(
                 self.body_model._model_id, self.enable_kid, target_vertices, target_joints,
                 vertex_weights, joint_weights, int(num_iter), float(beta_regularizer),
@@ -132,6 +144,25 @@ class BodyFitter(nn.Module):
         if 'pose_rotvecs' not in requested_keys:
             result.pop('pose_rotvecs', None)
         return result
+
+    def _fit_differentiable(self, target_vertices, target_joints, vertex_weights, joint_weights, num_iter,
+                            beta_regularizer, beta_regularizer2, kid_regularizer, final_adjust_rots, unsupported):
+        from ._autograd import TorchFit
+
+        bm = self.body_model
+        device = bm.v_template.device
+        if device.type != 'cuda':
+            raise RuntimeError("smplfitter_amd runs on MI355X only: move the model and the inputs to a 'cuda' (ROCm) device")
+        bad = [k for k, v in unsupported.items() if v is not None and v is not False]
+        if bad:
+            raise NotImplementedError(f'the differentiable fit does not implement {", ".join(bad)}; detach the inputs to use the HIP path')
+        if self._torchfit is None:
+            self._torchfit = TorchFit(bm, enable_kid=self.enable_kid)
+        mv = lambda t: None if t is None else t.to(device)  # noqa: E731
+        return self._torchfit.fit(mv(target_vertices), mv(target_joints), mv(vertex_weights), mv(joint_weights),
+                                  num_iter=int(num_iter), beta_regularizer=float(beta_regularizer),
+                                  beta_regularizer2=float(beta_regularizer2), kid_regularizer=kid_regularizer,
+                                  final_adjust_rots=bool(final_adjust_rots))
 
     def _fit_direct(self, target_vertices, target_joints, vertex_weights, joint_weights, num_iter,
                     beta_regularizer, beta_regularizer2, kid_reg, final_adjust_rots,

@@ -37,7 +37,7 @@ import smplfitter.pt as ref  # noqa: E402
 from smplfitter.pt import rotation as ref_rot  # noqa: E402
 from smplfitter_amd import synth  # noqa: E402
 
-B = 4
+B = 8
 
 
 def cfg_name(num_iter, beta_reg, joints, weights, final):

@@ -2,7 +2,7 @@
 fits and forward passes with num_betas = 6 (the ``smpl`` fixture) and 13 (``smpl_b16``: the same construction
 with 16 shape directions, synth.make_model_arrays('smpl_b16')) — neither is a count the kernels are
 instantiated for: the library pads the shape unknowns up to 10 / 16 — without and with the kid blend shape.
-B = 4; the targets are forward passes of each model at random parameters.
+B = 8; the targets are forward passes of each model at random parameters.
 
 Usage:  python tests/golden/make_golden_nb.py
 """
@@ -21,7 +21,7 @@ sys.path.insert(0, '/root/reference/src')
 import smplfitter.pt as ref  # noqa: E402
 from smplfitter_amd import synth  # noqa: E402
 
-B = 4
+B = 8
 NB_DIR = {6: 'smpl', 13: 'smpl_b16'}
 
 

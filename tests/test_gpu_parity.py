@@ -89,6 +89,7 @@ def test_general_goldens(kind, model_root, golden, dev):
     assert m.num_betas == int(gg[f'{kind}.num_betas'])
     info = m._native(dev).info
     assert info.vertex_path == _lib.SMPLFIT_PATH_GENERAL and info.num_betas == m.num_betas
+    assert m.kernel_path() == 'general'
     md = util.load_general_md(model_root, kind)
     om64 = util.O.OracleModel(md, np.float64, 'smpl')
     pre = kind + '.'
@@ -129,6 +130,61 @@ def test_general_goldens(kind, model_root, golden, dev):
     assert all(np.array_equal(a[k], b[k]) for k in a)
 
 
+@pytest.mark.parametrize('kind,B', [('smpl_b32', 1024), ('smpl_w12', 1024), ('smpl_b300', 96)])
+def test_general_full_size(kind, B, model_root, dev):
+    """The general path at larger batches on fresh seeded inputs (+ 5 mm noise): samples against the fp64 oracle, run to
+    run bit-identical, a slice fitted alone gives the same bits, the other entry points (known shape / known pose)."""
+    from smplfitter_amd.pt import BodyFitter, BodyModel
+
+    nb = util.GENERAL_KINDS[kind]
+    m = BodyModel('smpl', 'neutral', model_root=f'{model_root}/{kind}', num_betas=nb, device=dev)
+    f = BodyFitter(m)
+    S, J = m.num_betas, m.num_joints
+    rs = np.random.RandomState(99)
+    pose = (rs.randn(B, 3 * J) * 0.1).astype(np.float32)
+    betas = (rs.randn(B, S) * (0.5 if S <= 32 else 0.15)).astype(np.float32)
+    trans = rs.randn(B, 3).astype(np.float32)
+    fw = m(t(pose, dev), t(betas, dev), t(trans, dev))
+    g = torch.Generator(device='cpu').manual_seed(5)
+    tv = fw['vertices'] + (torch.randn(fw['vertices'].shape, generator=g) * 0.005).to(dev)
+    tj = fw['joints']
+    r = f.fit(tv, tj, num_iter=3, beta_regularizer=1.0, requested_keys=['pose_rotvecs'])
+    r2 = f.fit(tv, tj, num_iter=3, beta_regularizer=1.0, requested_keys=['pose_rotvecs'])
+    for k in ('pose_rotvecs', 'shape_betas', 'trans'):
+        assert torch.isfinite(r[k]).all() and torch.equal(r[k], r2[k]), k
+    s = slice(B // 2 - 7, B // 2 + 9)
+    r3 = f.fit(tv[s], tj[s], num_iter=3, beta_regularizer=1.0, requested_keys=['pose_rotvecs'])
+    for k in ('pose_rotvecs', 'shape_betas', 'trans'):
+        assert torch.equal(r[k][s], r3[k]), k
+    md = util.load_general_md(model_root, kind)
+    om64, om32 = util.O.OracleModel(md, np.float64, 'smpl'), util.O.OracleModel(md, np.float32, 'smpl')
+    idx = np.array([0, 1, B // 3, B // 2, B - 2, B - 1])
+    tvn, tjn = tv[idx].cpu().numpy(), tj[idx].cpu().numpy()
+    ref = util.O.OracleFitter(om64).fit(tvn, tjn, num_iter=3, beta_regularizer=1.0)
+    ref32 = util.O.OracleFitter(om32).fit(tvn, tjn, num_iter=3, beta_regularizer=1.0)
+    o = {k: r[k][idx].cpu().numpy() for k in ('pose_rotvecs', 'shape_betas', 'trans')}
+    err = util.vertex_l2(om64, o, ref)
+    floor = util.vertex_l2(om64, ref32, ref)  # the fp32 restatement's own distance to the fp64 arbiter
+    print(f'[general full] {kind} B={B}: vtx {err:.2e} (fp32 oracle floor {floor:.2e})')
+    assert err < max(2 * floor, 3e-5) and err < 1e-4
+    # the reference's round-trip acceptance test (tests/test_fitter_common.py:31-72): clean targets, no ridge, < 5e-3 m mean
+    r0 = f.fit(fw['vertices'], tj, num_iter=3, beta_regularizer=0.0, requested_keys=['pose_rotvecs'])
+    fw2 = m(r0['pose_rotvecs'], r0['shape_betas'], r0['trans'])
+    assert (fw2['vertices'] - fw['vertices']).norm(dim=-1).mean().item() < 5e-3
+    # known shape / known pose on the same kernels
+    ks = f.fit_with_known_shape(shape_betas=t(betas, dev), target_vertices=tv, target_joints=tj, num_iter=2,
+                                requested_keys=['pose_rotvecs'])
+    refks = util.O.OracleFitter(om64).fit_with_known_shape(betas[idx], tvn, tjn, num_iter=2)
+    va = om64.forward(ks['pose_rotvecs'][idx].cpu().numpy(), betas[idx], ks['trans'][idx].cpu().numpy())['vertices']
+    vb = om64.forward(refks['pose_rotvecs'], betas[idx], refks['trans'])['vertices']
+    assert np.linalg.norm(va - vb, axis=-1).max() < 1e-4
+    kp = f.fit_with_known_pose(pose_rotvecs=t(pose, dev), target_vertices=tv, target_joints=tj, beta_regularizer=1.0)
+    refkp = util.O.OracleFitter(om64).fit_with_known_pose(pose[idx], tvn, tjn, beta_regularizer=1.0)
+    va = om64.forward(pose[idx], kp['shape_betas'][idx].cpu().numpy(), kp['trans'][idx].cpu().numpy())['vertices']
+    vb = om64.forward(pose[idx], refkp['shape_betas'], refkp['trans'])['vertices']
+    assert np.linalg.norm(va - vb, axis=-1).max() < 1e-4
+
+
 @pytest.fixture(params=['batch-major', 'wave-per-instance'])
 def vertex_path(request, smplfit_env):
     """The default fit takes the batch-major vertex kernels where they apply (unit vertex weights, joints
@@ -150,7 +206,7 @@ def test_fit_goldens(name, model_root, golden, dev, vertex_path):
     # <= 2.2e-4 on all 32 option combinations; the reference's own fp32 floor is 3e-4); the
     # thin-finger SMPL-X fixture is ill-conditioned in the reference itself (pt vs fp64: 5e-4) and is judged
     # on vertices (its fat-part twin is gated in test_gpu_evidence.py::test_parity_statistics)
-    pose_tol = 5e-3 if name in ('smplx', 'smplx_w6') else 3e-4
+    pose_tol = util.pose_tol(name) if name in ('smplx', 'smplx_w6') else 3e-4  # (3e-3 on the thin-finger fixtures, see util.pose_tol)
     beta_tol = 3e-4 if name in ('smplx', 'smplx_w6') else 1e-4
     for c in util.fit_configs(g):
         cfg = util.cfg_from_name(c)
@@ -310,7 +366,8 @@ def test_stage_half(model_root, golden, dev, smplfit_env):
         assert np.abs(o['pose_rotvecs'] - r['pose_rotvecs']).max() < 3e-4, c
 
 
-@pytest.mark.parametrize('name,B', [('smpl', 4096), ('smplx', 4096), ('smpl1024', 16384), ('smpl_w6', 4096), ('smpl_rnd', 4096)])
+@pytest.mark.parametrize('name,B', [('smpl', 4096), ('smplx', 4096), ('smpl1024', 16384), ('smpl_w6', 4096), ('smplx_w6', 2048),
+                                    ('smpl_rnd', 4096)])
 def test_full_size_properties(name, B, model_root, golden, dev, vertex_path):
     """BASELINE.json configs 2-4 at full size: round trip (the reference's own acceptance test,
     tests/test_fitter_common.py:31-72: mean vertex / joint error < 5e-3 m after fit -> forward),
@@ -510,7 +567,7 @@ def test_convert_vertices_sparse(model_root, golden, dev, tmp_path, monkeypatch)
     v = t(g['target_vertices'], dev)
     out = conv.convert_vertices(v).cpu().numpy()
     ref = np.einsum('ov,bvc->boc', mat.toarray(), g['target_vertices'])
-    assert out.shape == (4, 10475, 3) and np.abs(out - ref).max() < 1e-5
+    assert out.shape == (v.shape[0], 10475, 3) and np.abs(out - ref).max() < 1e-5
 
 
 def test_transfer_matrix_shapes(dev):
@@ -1007,10 +1064,11 @@ def test_cached_fit_fn(model_root, golden, dev):
     assert get_cached_fit_fn(**kw) is fn
     tv, tj = t(g['target_vertices'], dev), t(g['target_joints'], dev)
     ref = f.fit(tv, tj, num_iter=3, beta_regularizer=1.0, requested_keys=['pose_rotvecs', 'shape_betas', 'trans'])
-    out = fn(tv.reshape(2, 2, -1, 3), tj.reshape(2, 2, -1, 3))
-    assert out['pose_rotvecs'].shape == (2, 2, 72) and out['orientations'].shape == (2, 2, 24, 3, 3)
+    B = tv.shape[0]
+    out = fn(tv.reshape(2, B // 2, -1, 3), tj.reshape(2, B // 2, -1, 3))
+    assert out['pose_rotvecs'].shape == (2, B // 2, 72) and out['orientations'].shape == (2, B // 2, 24, 3, 3)
     for k in ('pose_rotvecs', 'shape_betas', 'trans'):
-        assert torch.equal(out[k].reshape(4, -1), ref[k])
+        assert torch.equal(out[k].reshape(B, -1), ref[k])
 
 
 def test_cabi_error_paths(model_root, golden, dev):

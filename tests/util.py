@@ -105,7 +105,10 @@ def pose_tol(name):
     (the bone parts' twist comes from the vertices' off-axis spread) and are judged on the vertices; 1.5e-3 on the
     1024-vertex subset."""
     if name in ('smplx', 'smplx_w6'):
-        return 5e-3
+        # (round 5, B = 8 fixture: the reference's own fp32 result sits 7.9e-4 from the fp64 evaluation of its algorithm
+        # on this ill-conditioned fixture; two independent fp32 evaluations — the reference's and ours — are up to 2.0e-3
+        # apart (host emulation, it1_reg0_j_nw_nfa).  Rounds 1-4 gated this at 5e-3.)
+        return 3e-3
     return 3e-4 if name in ('smpl', 'smplxfat', 'smpl_w6', 'smpl_rnd') else 1.5e-3
 
 
@@ -309,17 +312,32 @@ def scale_inputs(g, case):
     return kid_fit, g['target_vertices'] * f, kw
 
 
-def check_scale(om, name, case, o, ge, kid_fit):
+def check_scale(om, name, case, o, ge, kid_fit, loose=1.0):
+    """``loose``: gate multiplier (3 for the fp32 numpy oracle, whose (S + 1)-unknown solve without a ridge is noisier than
+    the reference's own fp32: 1.4e-4 m on case b of the B = 8 fixture where its fp64 form and the HIP arithmetic sit at
+    1e-5)."""
     keys = ('pose_rotvecs', 'shape_betas', 'trans', 'scale_corr') + (('kid_factor',) if kid_fit else ())
     ref = {k: ge[f'scale.{case}.{k}'] for k in keys}
-    assert np.abs(o['scale_corr'] - ref['scale_corr']).max() < 1e-4, case  # the reference solves this system in fp32
-    assert np.abs(o['trans'] - ref['trans']).max() < 5e-5, case
+    if kid_fit:
+        # kid AND scale unknowns (case d): on the synthetic model the kid direction (0.6 x the template) is almost a pure
+        # scaling, so the two unknowns are nearly collinear and the reference's fp32 solve amplifies its own rounding — on
+        # the round-5 (B = 8) fixture its result sits 1.1e-4 m (mesh), 6.6e-5 (trans), 1.0e-4 (kid) from the fp64
+        # evaluation of the same algorithm, and an independent fp32 evaluation 3.5e-4 m from it.  Gates: 4x that distance.
+        assert np.abs(o['scale_corr'] - ref['scale_corr']).max() < 4e-4, case
+        assert np.abs(o['trans'] - ref['trans']).max() < 3e-4, case
+        assert np.abs(o['shape_betas'] - ref['shape_betas']).max() < 1e-3, case
+        va = om.forward(o['pose_rotvecs'], o['shape_betas'], o['trans'], kid_factor=o['kid_factor'])['vertices']
+        vb = om.forward(ref['pose_rotvecs'], ref['shape_betas'], ref['trans'], kid_factor=ref['kid_factor'])['vertices']
+        assert np.linalg.norm(va - vb, axis=-1).max() < 4.5e-4, case
+        return
+    assert np.abs(o['scale_corr'] - ref['scale_corr']).max() < 1e-4 * loose, case  # the reference solves this system in fp32
+    assert np.abs(o['trans'] - ref['trans']).max() < 5e-5 * loose, case
     assert np.abs(o['shape_betas'] - ref['shape_betas']).max() < (1e-3 if name == 'smpl' else 3e-3), case
     kw_o = dict(kid_factor=o['kid_factor']) if kid_fit else {}
     kw_r = dict(kid_factor=ref['kid_factor']) if kid_fit else {}
     va = om.forward(o['pose_rotvecs'], o['shape_betas'], o['trans'], **kw_o)['vertices']
     vb = om.forward(ref['pose_rotvecs'], ref['shape_betas'], ref['trans'], **kw_r)['vertices']
-    assert np.linalg.norm(va - vb, axis=-1).max() < 1e-4, case
+    assert np.linalg.norm(va - vb, axis=-1).max() < 1e-4 * loose, case
 
 
 # fit_with_known_pose with the options of the general shape solve (reference pt/bodyfitter.py:552-653 ->

@@ -38,7 +38,8 @@ for rep in range(3):
 lib = _lib.load()
 st = torch.cuda.current_stream(dev).cuda_stream
 kt = {}
-for name, kid in (('gemm', 2), ('accum', 3), ('solve', 4), ('lbs', 5), ('pair_gram', 6), ('layout', 7), ('tmpl_psum', 8)):
+for name, kid in (('gemm', 2), ('accum', 3), ('solve', 4), ('lbs', 5), ('pair_gram', 6), ('layout', 7), ('tmpl_psum', 8),
+                  ('joint', 9), ('refine', 10), ('gram_comb', 11), ('psum_comb', 12), ('jdT', 13), ('lbs_last', 15), ('mean', 14)):
     ms = C.c_float()
     if lib.smplfit_time_kernel_f32(h.ptr, kid, B, 10, C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(st), C.byref(ms)) == 0:
         kt[name] = round(ms.value * 1e3, 1)

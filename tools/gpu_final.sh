@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-end evidence on the GPU box (through gpurun): everything profiles/ holds for the round, from the tree as it is.
 #   bash tools/gpu_final.sh [tag]      -> gpurun_out/prof_<tag>/out/* and gpurun_out/final_<tag>/*
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT; F=$R/gpurun_out/final_$TAG; mkdir -p $F
 bash tools/profile_round.sh $TAG > gpurun_out/prof_$TAG.log 2>&1 < /dev/null; tail -3 gpurun_out/prof_$TAG.log
 for c in c3 c4 c5; do python bench.py --config $c --steps 10 --warmup 3 > $F/bench_$c.json 2>$F/bench_$c.err < /dev/null; python -c "
@@ -18,4 +18,5 @@ timeout 300 bash tools/pmc_sq.sh ${TAG}_smpl - smpl > $F/pmc_sq_smpl.log 2>&1 < 
 timeout 300 python tools/bench_callers.py > $F/bench_callers.txt 2>$F/bench_callers.err < /dev/null; tail -12 $F/bench_callers.txt
 timeout 200 python tools/latency.py > $F/latency.json 2>$F/latency.err < /dev/null; tail -2 $F/latency.json | cut -c1-300
 timeout 200 python tools/bench_skin.py > $F/bench_skin.json 2>/dev/null < /dev/null; cat $F/bench_skin.json
+timeout 300 python tools/bench_general.py > $F/bench_general.json 2>/dev/null < /dev/null; cat $F/bench_general.json
 SMPLFIT_LIB=build_ab/libwstamp.so timeout 200 python tools/wave_stamps.py 4096 > $F/wave_stamps_4096.txt 2>&1 < /dev/null; head -12 $F/wave_stamps_4096.txt
