@@ -20,9 +20,26 @@ struct PieceRun {  // a whole or split piece on its way into a share
   const int32_t* joints;
 };
 int piece_cost(int count) { return count + (count & 1) + kPieceCost; }
+// one piece record: 12 ints, or — pieces of up to eight joints — a pair of them, the second with joints / slots 4..7
+void emit_piece(std::vector<int32_t>& out, int NJ, int count, const int32_t* joints, const int* slots, int start, int row, int info) {
+  for (int half = 0; half < NJ / 4; ++half) {
+    int32_t rec[kPieceRec] = {0};
+    rec[0] = count;
+    for (int q = 0; q < 4; ++q) {
+      rec[1 + q] = joints[4 * half + q];
+      rec[5 + q] = slots ? slots[joints[4 * half + q]] : 0;
+    }
+    rec[9] = start;
+    rec[10] = row;
+    rec[11] = info;
+    out.insert(out.end(), rec, rec + kPieceRec);
+  }
+}
 
 void build_share_table(const HostTables& t, int kind, ShareTable& out, int cell_steps, int cell_cap) {
   out = ShareTable();
+  const int NJ = t.NJ, RS = t.piece_rec();
+  out.rec = RS;
   std::vector<PieceRun> dom;
   long total = 0;
   for (const auto& p : t.vpieces) {
@@ -112,16 +129,8 @@ void build_share_table(const HostTables& t, int kind, ShareTable& out, int cell_
           ++b;
         }
         for (size_t i = a; i < b; ++i) {
-          int32_t rec[kPieceRec] = {0};
-          rec[0] = ps[i].count;
-          for (int q = 0; q < 4; ++q) {
-            rec[1 + q] = ps[i].joints[q];
-            rec[5 + q] = slots[ps[i].joints[q]];
-          }
-          rec[9] = ps[i].start;
-          rec[10] = i + 1 == b ? row : -1;
-          rec[11] = (i + 1 == b ? nq : 0) | (i + 1 == ps.size() ? (k + 1) << 8 : 0);
-          out.pieces.insert(out.pieces.end(), rec, rec + kPieceRec);
+          emit_piece(out.pieces, NJ, ps[i].count, ps[i].joints, slots, ps[i].start, i + 1 == b ? row : -1,
+                     (i + 1 == b ? nq : 0) | (i + 1 == ps.size() ? (k + 1) << 8 : 0));
           cost += piece_cost(ps[i].count);
         }
         for (int q = 0; q < kGroupJoints; ++q) out.row_joints.push_back(q < nq ? order[q] : -1);
@@ -131,12 +140,7 @@ void build_share_table(const HostTables& t, int kind, ShareTable& out, int cell_
     } else {
       for (size_t i = 0; i < ps.size(); ++i) {
         const bool last = i + 1 == ps.size() || ps[i + 1].part != ps[i].part;
-        int32_t rec[kPieceRec] = {0};
-        rec[0] = ps[i].count;
-        for (int q = 0; q < 4; ++q) rec[1 + q] = ps[i].joints[q];
-        rec[9] = ps[i].start;
-        rec[10] = last ? row : -1;
-        out.pieces.insert(out.pieces.end(), rec, rec + kPieceRec);
+        emit_piece(out.pieces, NJ, ps[i].count, ps[i].joints, nullptr, ps[i].start, last ? row : -1, 0);
         cost += piece_cost(ps[i].count);
         if (last) {
           out.row_part.push_back(ps[i].part);
@@ -145,10 +149,10 @@ void build_share_table(const HostTables& t, int kind, ShareTable& out, int cell_
       }
     }
     out.max_cost = std::max(out.max_cost, cost);
-    out.piece_start.push_back((int32_t)(out.pieces.size() / kPieceRec));
+    out.piece_start.push_back((int32_t)(out.pieces.size() / RS));
   }
   out.nrows = row;
-  out.pieces.insert(out.pieces.end(), kPieceRec, 0);  // sentinel
+  out.pieces.insert(out.pieces.end(), RS, 0);  // sentinel
   for (int k = 0; k < ns; ++k)
     if (out.piece_start[k + 1] == out.piece_start[k]) {  // (an empty cell: no table, see build_share_tables)
       if (std::getenv("SMPLFIT_DUMP_SHARES")) std::fprintf(stderr, "kind %d: cell %d of %d is empty (total %ld)\n", kind, k, ns, total);
@@ -373,6 +377,7 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
   }
   t.general = general;
   t.KW = max_nnz <= 4 ? 4 : (max_nnz <= 8 ? 8 : round_up(max_nnz, 4));
+  t.NJ = t.KW == 8 ? 8 : 4;
 
   // ---- sorted slots: used parts first (by part id, stable), then the rest ----
   std::vector<int> order(V);
@@ -528,17 +533,17 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
     const int bs = t.brec_stride(), bw = t.brec_w();
     t.brec.assign((size_t)Vp * bs, 0.f);
     t.vpieces.clear();
-    for (int i = 0; i < V && t.KW == 4;) {  // (models with more than four weights per vertex never take these kernels)
+    for (int i = 0; i < V;) {  // pieces of at most NJ joints (4, or 8 for models with 5-8 weights per vertex)
       const int p = t.slot_part[i];
       uint64_t u = 0;
       int e = i;
       while (e < V && t.slot_part[e] == p) {
         const uint64_t u2 = u | jmask[t.perm[e]];
-        if (__builtin_popcountll(u2) > 4) break;
+        if (__builtin_popcountll(u2) > t.NJ) break;
         u = u2;
         ++e;
       }
-      if (e == i) return "smplfit_create: a vertex of the batch-major tables has more than 4 skinning joints";
+      if (e == i) return "smplfit_create: a vertex of the batch-major tables has more skinning joints than a piece holds";
       VertexPiece pc{};
       pc.start = i;
       pc.count = e - i;
@@ -547,7 +552,7 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
       for (int j = 0; j < J; ++j)
         if ((u >> j) & 1) pc.joints[pc.nj++] = j;
       if (pc.nj == 0) pc.joints[pc.nj++] = p;  // (a vertex without weights: cannot happen for a valid model)
-      for (int k = pc.nj; k < 4; ++k) pc.joints[k] = pc.joints[0];  // padding joints carry weight 0
+      for (int k = pc.nj; k < 8; ++k) pc.joints[k] = pc.joints[0];  // padding joints carry weight 0
       for (int v = i; v < e; ++v) {  // the vertex's weights in the piece's joint order
         float* r = t.brec.data() + (size_t)v * bs;
         for (int k = 0; k < pc.nj; ++k) r[bw + k] = d.weights[(size_t)t.perm[v] * J + pc.joints[k]];

@@ -41,7 +41,7 @@ struct Segment {
 // piece's joint order (ascending joint id).
 struct VertexPiece {
   int32_t start, count, part, used, nj;
-  int32_t joints[4];  // ascending, padded with joints[0] (padding joints carry weight 0)
+  int32_t joints[8];  // ascending, padded with joints[0] (padding joints carry weight 0); HostTables::NJ of them are used
 };
 // The work of one instance block (64 instances) is cut into NC CELLS: runs of whole or split pieces of (nearly) equal
 // cost — cost = steps (a piece of odd length takes one padding step) + kPieceCost per piece (the exposed load of its
@@ -89,6 +89,9 @@ constexpr int kPieceCost = SMPLFIT_PIECE_COST;
 // segment, [9] first slot, [10] the output row block written AFTER this piece (-1: none), [11] residual tables: the
 // row's joint count | (cell index + 1) << 8 behind the LAST piece of a cell (there the wave also writes the cell's
 // r1 | Sb record).  Every table ends with one all-zero record: reading one record past the last piece is valid.
+// Models with 5-8 skinning weights per vertex (HostTables::NJ == 8, round 5): a piece holds up to EIGHT joints and its
+// record is a PAIR of such records — the second one carries joints 4..7 in [1..4] and their local slots in [5..8] (its
+// other fields repeat the first one's): piece_rec() = 24.
 constexpr int kPieceRec = 12;
 enum ShareKind : int {
   kShareResidual = 0,  // all slots; a row = a SEGMENT (run of pieces of one cell whose joints number <= kGroupJoints): moments
@@ -101,6 +104,7 @@ enum ShareKind : int {
 };
 struct ShareTable {
   int ncells = 0, nrows = 0, max_cost = 0;
+  int rec = kPieceRec;               // ints per piece record (HostTables::piece_rec())
   std::vector<int32_t> piece_start;  // (ncells + 1)
   std::vector<int32_t> pieces;       // (npieces + 1, kPieceRec)
   std::vector<int32_t> row_part;     // (nrows) LBS tables: the part of a row
@@ -114,6 +118,8 @@ struct HostTables {
                                    // are built for 10 / 16 betas, a model with fewer is padded up (unit ridge)
   int num_betas() const { return S - n_kid - n_pad; }  // the caller's betas
   int Vp = 0, Kp = 0, KW = 4;
+  int NJ = 4;                      // joints of a vertex piece of the batch-major kernels: 4 (KW == 4) or 8 (KW == 8)
+  int piece_rec() const { return NJ == 8 ? 2 * kPieceRec : kPieceRec; }
   // max over vertices of |sum of skinning weights - 1|: the batch-major residual kernel derives the residual sum
   // from the per-joint moments, which is exact only for normalised weights (the other kernels keep the sum explicitly)
   float wsum_dev = 0.f;
@@ -207,10 +213,10 @@ struct HostTables {
   std::vector<float> diag_c2e;   // diag_c2 as (J, 3, SE)
   int s_even() const { return (S + 1) & ~1; }
   // brec row (brec_stride() floats, fetched with scalar loads): [sd_x : S][sd_y : S][sd_z : S][pad to a
-  // multiple of 4][4 weights in the joint order of the vertex's piece]
+  // multiple of 4][NJ weights in the joint order of the vertex's piece]
   std::vector<float> brec;       // (Vp, brec_stride())
   int brec_w() const { return (3 * S + 3) / 4 * 4; }  // offset of the weights
-  int brec_stride() const { return brec_w() + 4; }
+  int brec_stride() const { return brec_w() + NJ; }
   std::vector<float> gblob;      // (ngt, gblob_stride())
   int gblob_stride() const { return 64 * cstride() + 16 * 64 + 16; }
 

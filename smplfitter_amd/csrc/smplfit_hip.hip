@@ -92,6 +92,7 @@ struct ShareView {
   // joint's residual moments, CSR (mb_start (J + 1), mb_row)
   const int32_t *aux_start, *aux_rows;
   int ncells, nrows;
+  int rec;   // ints per piece record: 12, or 24 for pieces of up to eight joints (sf::HostTables::piece_rec)
   int mult;  // cells per wave: share s walks the cells [s * mult, (s + 1) * mult)
   int fine;  // the fine table of its kind (small batches): the combine kernels split the rows over waves
 };
@@ -457,7 +458,8 @@ bool bm_applies(const DevModel& d) {
   // (normalised skinning weights are checked where the handle is at hand: bm_applies(const smplfit_handle*))
   // Vp > V: the batch-major loops run their out-of-range steps on the first padding slot
   // (below ~1000 vertices the prologue of a wave outweighs its vertex work)
-  return use_bm() && d.KW == 4 && (d.S == 10 || d.S == 11) && d.bm_tables && d.V >= 1024 && d.Vp > d.V;
+  // (KW == 8 since round 5: pieces of up to eight joints, two waves per SIMD — 5-8 skinning weights per vertex)
+  return use_bm() && (d.KW == 4 || d.KW == 8) && (d.S == 10 || d.S == 11) && d.bm_tables && d.V >= 1024 && d.Vp > d.V;
 }
 
 // The batch-major residual kernel derives sum_v b_v from the per-joint moments: exact only when every vertex's
@@ -518,7 +520,10 @@ void launch_residual_bm_s(const smplfit_handle* h, const Workspace& ws, int B, h
   const DevModel& d = h->d;
   const int Mp = (int)align_up((size_t)B, 128);
   const ShareView sv = share_view(h, sf::kShareResidual, B);
-  if (which & 1)
+  if ((which & 1) && d.KW == 8)
+    hipLaunchKernelGGL((k_residual_bm<S, 8>), share_grid(sv, Mp), dim3(64 * kBW),
+                       std::max(kResidualLds, (size_t)tune().bm_lds_kb * 1024), st, d, sv, ws, B, Mp);
+  else if (which & 1)
     hipLaunchKernelGGL((k_residual_bm<S>), share_grid(sv, Mp), dim3(64 * kBW),
                        std::max(kResidualLds, (size_t)tune().bm_lds_kb * 1024), st, d, sv, ws, B, Mp);
   if (which & 2) {
@@ -572,26 +577,39 @@ void launch_lbs_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStrea
   const int Mp = (int)align_up((size_t)B, 128);
   const size_t lds = (size_t)tune().bm_lds_kb * 1024;
   const ShareView sv = share_view(h, write_v ? sf::kShareLbsAll : adj_only ? sf::kShareLbsAdj : sf::kShareLbsUsed, B);
-  if constexpr (KW == 4 && S <= 12) {  // what bm_applies admits (10 betas with or without the kid unknown)
+  if constexpr ((KW == 4 || KW == 8) && S <= 12) {  // what bm_applies admits (10 betas with or without the kid unknown)
     if (write_v) {
       // (write_all: every posed vertex — the alignment sums of a known-shape fit; else the slots the regressor reads)
       const int wa = write_all ? 1 : 0;
       if (weighted)
-        hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4, true, false, true>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp, wa);
+        hipLaunchKernelGGL((k_lbs_partsum_bm<S, KW, true, false, true>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp, wa);
       else
-        hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4, true>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp, wa);
+        hipLaunchKernelGGL((k_lbs_partsum_bm<S, KW, true>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp, wa);
       // regress: the regressed reference joints are consumed (joints-omitted fits).  A known-shape fit WITH target
       // joints keeps the posed mesh for its alignment sums only; and a model without a regressor has none to apply
       const bool do_regress = (regress < 0 ? true : regress != 0) && h->t.has_regressor;
       if (do_regress)
         hipLaunchKernelGGL(k_regress_joints_bm<false>, dim3(Mp / 64, d.J), dim3(64), 0, st, d, ws.vpT, nullptr, ws.rjreg, B);
     } else if (weighted) {
-      hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4, false, false, true>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp);
+      hipLaunchKernelGGL((k_lbs_partsum_bm<S, KW, false, false, true>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp);
     } else {
-      hipLaunchKernelGGL((k_lbs_partsum_bm<S, 4>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp);
+      hipLaunchKernelGGL((k_lbs_partsum_bm<S, KW>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp);
     }
   }
   launch_psum_combine(d, sv, ws, B, Mp, st);
+}
+
+// the forward-only variant of the batch-major LBS pass (posed vertices left in ws.vpT): input side of a fused
+// conversion, BodyModel.forward, the mesh of a shape solve
+void launch_lbs_fwd_bm(const DevModel& d, const ShareView& sv, const Workspace& ws, int B, int Mp, hipStream_t st) {
+  const dim3 grid = share_grid(sv, Mp);
+  if (d.KW == 8) {
+    if (d.S == 11) hipLaunchKernelGGL((k_lbs_partsum_bm<11, 8, true, true>), grid, dim3(64 * kBW), 0, st, d, sv, ws, B, Mp);
+    else hipLaunchKernelGGL((k_lbs_partsum_bm<10, 8, true, true>), grid, dim3(64 * kBW), 0, st, d, sv, ws, B, Mp);
+  } else {
+    if (d.S == 11) hipLaunchKernelGGL((k_lbs_partsum_bm<11, 4, true, true>), grid, dim3(64 * kBW), 0, st, d, sv, ws, B, Mp);
+    else hipLaunchKernelGGL((k_lbs_partsum_bm<10, 4, true, true>), grid, dim3(64 * kBW), 0, st, d, sv, ws, B, Mp);
+  }
 }
 
 template <int S, int KW>
@@ -864,6 +882,10 @@ inline bool stage_half(const DevModel& d, int bit, int B) {
   return (SMPLFIT_STAGE_HALF & bit) && d.J <= 32 && B >= tune().stage_half_b && !d.general;
 }
 
+void launch_forward_joint(const DevModel& d, const ForwardArgs& fa, const Workspace& ws, int B, hipStream_t st) {
+  if (d.general) hipLaunchKernelGGL(k_forward_joint<true>, dim3(B), dim3(64), joint_lds(d), st, d, fa, ws);
+  else hipLaunchKernelGGL(k_forward_joint<false>, dim3(B), dim3(64), joint_lds(d), st, d, fa, ws);
+}
 void launch_joint_stage(const DevModel& d, JointStageArgs ja, const Workspace& ws, int B, hipStream_t st) {
   ja.B = B;
   ja.b0 = 0;
@@ -874,7 +896,8 @@ void launch_joint_stage(const DevModel& d, JointStageArgs ja, const Workspace& w
       hipLaunchKernelGGL(k_joint_stage<64>, dim3(1), dim3(64), joint_lds(d), st, d, ja, ws);
     }
   } else {
-    hipLaunchKernelGGL(k_joint_stage<64>, dim3(B), dim3(64), joint_lds(d), st, d, ja, ws);
+    if (d.general) hipLaunchKernelGGL((k_joint_stage<64, true>), dim3(B), dim3(64), joint_lds(d), st, d, ja, ws);
+    else hipLaunchKernelGGL(k_joint_stage<64>, dim3(B), dim3(64), joint_lds(d), st, d, ja, ws);
   }
 }
 void launch_refine(const DevModel& d, RefineArgs ra, const Workspace& ws, int B, hipStream_t st) {
@@ -899,8 +922,12 @@ void launch_shape_solve(const DevModel& d, const Workspace& ws, int B, hipStream
       hipLaunchKernelGGL(k_shape_solve<64>, dim3(1), dim3(64), solve_lds(d), st, d, ws, B, beta_reg, beta_reg2,
                          kid_reg, pair_form, use_ref, mode, B - 1);
   } else {
-    hipLaunchKernelGGL(k_shape_solve<64>, dim3(B), dim3(64), solve_lds(d), st, d, ws, B, beta_reg, beta_reg2,
-                       kid_reg, pair_form, use_ref, mode, 0);
+    if (d.general)
+      hipLaunchKernelGGL((k_shape_solve<64, true>), dim3(B), dim3(64), solve_lds(d), st, d, ws, B, beta_reg, beta_reg2,
+                         kid_reg, pair_form, use_ref, mode, 0);
+    else
+      hipLaunchKernelGGL(k_shape_solve<64>, dim3(B), dim3(64), solve_lds(d), st, d, ws, B, beta_reg, beta_reg2,
+                         kid_reg, pair_form, use_ref, mode, 0);
   }
 }
 
@@ -1019,8 +1046,9 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   // wave-per-instance kernels)
   // scale_target / scale_fit: the LAST iteration's solve has one more unknown and needs extra vertex sums — that
   // iteration runs the accumulate kernel (with or without weights) in its EXTRAS form
-  const bool bm_base = bm_applies(h) && !o.rotations_only && (!o.scale_mode || (tune().bm_scale && d.S == 10));
-  const bool bm = bm_base && (!vw || (tune().bm_weighted && (!eff_v || d.S == 10)));
+  // (the accumulate kernel k_accum_w_bm — vertex weights in the solve, the scaled iteration — holds four joints per piece)
+  const bool bm_base = bm_applies(h) && !o.rotations_only && (!o.scale_mode || (tune().bm_scale && d.S == 10 && d.KW == 4));
+  const bool bm = bm_base && (!vw || (tune().bm_weighted && (!eff_v || (d.S == 10 && d.KW == 4))));
   if (o.source && !bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "fused conversion: the batch-major path does not apply");
   // (a warm-started fit evaluates its first part sums against the posed initial model: on the batch-major path with
   // the LBS pass of the iterations — until round 4 with the wave-per-instance kernel over a second, sorted copy)
@@ -1066,14 +1094,14 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     fa.joints = ws.rjoints;
     fa.orient = ws.G;
     if (on(0) && bm) {
-      hipLaunchKernelGGL(k_forward_joint, dim3(B), dim3(64), joint_lds(d), st, d, fa, ws);
+      launch_forward_joint(d, fa, ws, B, st);
       if (int rc = launch_gemm(d, ws, B, st, true)) return rc;
       launch_jd_transpose(d, ws, B, st);
 #define SF_CALL_LBS(S_, KW_) launch_lbs_bm<S_, KW_>(h, ws, B, st, !joints, false, vweighted)
       SF_DISPATCH_SKW(d, SF_CALL_LBS);
 #undef SF_CALL_LBS
     } else if (on(0)) {
-      hipLaunchKernelGGL(k_forward_joint, dim3(B), dim3(64), joint_lds(d), st, d, fa, ws);
+      launch_forward_joint(d, fa, ws, B, st);
       launch_gemm(d, ws, B, st);
       if (int rc = launch_lbs_any<1>(d, ws, B, vweighted, d.S, ws.beta, ws.trans, nullptr, st)) return rc;
       if (!joints)
@@ -1224,7 +1252,7 @@ int run_fit_known_shape(const smplfit_handle* h, const float* betas, int nb, con
   ja.rj_shared = 0;
   ja.Gprev = ws.G;
   for (int it = 0; it <= o.num_iter; ++it) {
-    hipLaunchKernelGGL(k_forward_joint, dim3(B), dim3(64), joint_lds(d), st, d, fa, ws);
+    launch_forward_joint(d, fa, ws, B, st);
     if (bm) {
       if (int rc = launch_gemm(d, ws, B, st, true)) return rc;
       launch_jd_transpose(d, ws, B, st);
@@ -1308,16 +1336,13 @@ int launch_convert_source(const ConvertSource& src, const DevModel& d, const Wor
   fa.betas = wi.beta;  // (B,S) rows, zero beyond the given betas
   fa.nb = di.S;
   fa.joints = wi.rjoints;
-  hipLaunchKernelGGL(k_forward_joint, dim3(B), dim3(64), joint_lds(di), st, di, fa, wi);
+  launch_forward_joint(di, fa, wi, B, st);
   if (int rc = launch_gemm(di, wi, B, st, true)) return rc;
   launch_jd_transpose(di, wi, B, st);
   {
     const ShareView sv = share_view(pl.in, sf::kShareLbsAll, B);
     const dim3 grid = share_grid(sv, Mp);
-    if (di.S == 11)
-      hipLaunchKernelGGL((k_lbs_partsum_bm<11, 4, true, true>), grid, dim3(64 * kBW), 0, st, di, sv, wi, B, Mp);
-    else
-      hipLaunchKernelGGL((k_lbs_partsum_bm<10, 4, true, true>), grid, dim3(64 * kBW), 0, st, di, sv, wi, B, Mp);
+    launch_lbs_fwd_bm(di, sv, wi, B, Mp, st);
   }
   TransferTabs tt{pl.d_oslot, pl.d_start, pl.d_islot, pl.d_w, d.V};
   hipLaunchKernelGGL(k_transfer_bm, dim3(pl.nslab, Mp / 64), dim3(256), 0, st, tt, wi.vpT, di.Vp, ws.tT, d.Vp, ws.resP, Mp);
@@ -1559,7 +1584,7 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
   }
   // stage images of the tiled split-bf16 GEMM (94 MB for SMPL-X): only for a model whose fits can take the
   // batch-major path (the only launches that read them; the structural part of bm_applies)
-  if (h->t.KW == 4 && (h->t.S == 10 || h->t.S == 11) && h->t.wsum_dev <= 1e-5f)
+  if ((h->t.KW == 4 || h->t.KW == 8) && (h->t.S == 10 || h->t.S == 11) && h->t.wsum_dev <= 1e-5f)
     sf::build_tiled_gemm_images(h->t);
   const sf::HostTables& t = h->t;
   DevModel& d = h->d;
@@ -1670,6 +1695,7 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
       ShareView& sv = h->views[i];
       sv.ncells = stb.ncells;
       sv.nrows = stb.nrows;
+      sv.rec = stb.rec;
       sv.mult = 1;
       up(stb.piece_start, &sv.piece_start);
       up(stb.pieces, &sv.pieces);
@@ -1976,7 +2002,7 @@ int smplfit_forward_ex_f32(const smplfit_handle* h, const smplfit_forward_args* 
   fa.trans = trans;
   fa.joints = joints;
   fa.orient = args->orientations;
-  hipLaunchKernelGGL(k_forward_joint, dim3(batch), dim3(64), joint_lds(d), st, d, fa, ws);
+  launch_forward_joint(d, fa, ws, batch, st);
   if (vertices && bm_applies(h) && tune().bm_forward) {
     // the batch-major kernels (round 4; what the input side of a fused conversion runs): shape / translation rows, the
     // transposed GEMM, the forward-only LBS pass over every slot (posed vertices in place in ws.vpT), and the inverse
@@ -1988,8 +2014,7 @@ int smplfit_forward_ex_f32(const smplfit_handle* h, const smplfit_forward_args* 
     launch_jd_transpose(d, ws, batch, st);
     const ShareView sv = share_view(h, sf::kShareLbsAll, batch);
     const dim3 grid = share_grid(sv, Mp);
-    if (d.S == 11) hipLaunchKernelGGL((k_lbs_partsum_bm<11, 4, true, true>), grid, dim3(64 * kBW), 0, st, d, sv, ws, batch, Mp);
-    else hipLaunchKernelGGL((k_lbs_partsum_bm<10, 4, true, true>), grid, dim3(64 * kBW), 0, st, d, sv, ws, batch, Mp);
+    launch_lbs_fwd_bm(d, sv, ws, batch, Mp, st);
     hipLaunchKernelGGL(k_unlayout_vertices, dim3((d.V + kSlabV - 1) / kSlabV, Mp / 64), dim3(256), (size_t)64 * kSlabRow * 4, st, d,
                        ws.vpT, vertices, batch);
   } else if (vertices) {
@@ -2060,8 +2085,9 @@ int smplfit_shape_solve_ex_f32(const smplfit_handle* h, const smplfit_shape_solv
   // the batch-major vertex kernels (round 4): streams, transposed GEMM, residual pass + pair-Gram (unit weights) or the
   // accumulate kernel (vertex weights in the solve / a scale unknown), as one iteration of fit()
   const bool scaled = o.scale_mode != 0;
-  const bool bm = bm_applies(h) && tune().bm_known_pose && (!vertex_weights || (tune().bm_weighted && (!eff_v || d.S == 10))) &&
-                  (!scaled || (tune().bm_scale && d.S == 10));
+  const bool bm = bm_applies(h) && tune().bm_known_pose &&
+                  (!vertex_weights || (tune().bm_weighted && (!eff_v || (d.S == 10 && d.KW == 4)))) &&
+                  (!scaled || (tune().bm_scale && d.S == 10 && d.KW == 4));
   const int Mp = (int)align_up((size_t)batch, 128);
   if (bm) {
     const int nslab = (d.V + kSlabV - 1) / kSlabV;
@@ -2114,8 +2140,7 @@ int smplfit_shape_solve_ex_f32(const smplfit_handle* h, const smplfit_shape_solv
   if (args->vertices_out && bm) {  // the mesh at the solution: forward-only LBS pass + the inverse of the target layout
     const ShareView sv = share_view(h, sf::kShareLbsAll, batch);
     const dim3 grid = share_grid(sv, Mp);
-    if (d.S == 11) hipLaunchKernelGGL((k_lbs_partsum_bm<11, 4, true, true>), grid, dim3(64 * kBW), 0, st, d, sv, ws, batch, Mp);
-    else hipLaunchKernelGGL((k_lbs_partsum_bm<10, 4, true, true>), grid, dim3(64 * kBW), 0, st, d, sv, ws, batch, Mp);
+    launch_lbs_fwd_bm(d, sv, ws, batch, Mp, st);
     hipLaunchKernelGGL(k_unlayout_vertices, dim3((d.V + kSlabV - 1) / kSlabV, Mp / 64), dim3(256), (size_t)64 * kSlabRow * 4, st, d,
                        ws.vpT, args->vertices_out, batch);
   } else if (args->vertices_out) {
@@ -2337,8 +2362,9 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
         return 0;
       case SMPLFIT_KERNEL_LBS_PARTSUM: {
         if (bm) {
-          if (d.S == 11) launch_lbs_bm<11, 4>(h, ws, batch, st);
-          else launch_lbs_bm<10, 4>(h, ws, batch, st);
+#define SF_CALL_LBS(S_, KW_) launch_lbs_bm<S_, KW_>(h, ws, batch, st)
+          SF_DISPATCH_SKW(d, SF_CALL_LBS);
+#undef SF_CALL_LBS
           return 0;
         }
         if (int rc = launch_lbs_any<0>(d, ws, batch, false, d.S, ws.beta, ws.trans, nullptr, st)) return rc;
@@ -2396,8 +2422,9 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
         return 0;
       case SMPLFIT_KERNEL_LBS_LAST:
         if (!bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "last LBS pass: batch-major path not active");
-        if (d.S == 11) launch_lbs_bm<11, 4>(h, ws, batch, st, false, true);
-        else launch_lbs_bm<10, 4>(h, ws, batch, st, false, true);
+#define SF_CALL_LBS(S_, KW_) launch_lbs_bm<S_, KW_>(h, ws, batch, st, false, true)
+        SF_DISPATCH_SKW(d, SF_CALL_LBS);
+#undef SF_CALL_LBS
         return 0;
       default: return fail(SMPLFIT_ERR_BAD_ARG, "smplfit_time_kernel_f32: unknown kernel id");
     }

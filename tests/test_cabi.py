@@ -79,25 +79,21 @@ def test_host_tables_match_reference_structure(lib, name, model_root, golden):
     for s, c, p in seg:  # every segment is one part, at most one wave wide
         assert 0 < c <= 64 and (of.part[perm[s:s + c]] == p).all()
     assert h.info.padded_vertices % 128 == 0
-    if name.endswith('_w6'):  # six weights per vertex: eight pairs, no batch-major tables (wave-per-instance kernels)
-        assert h.info.skin_width == 8 and len(h.table('vertex_pieces')) == 0 and len(h.table('cell_counts')) == 0
-        assert h.workspace_bytes(64) > 0
-        h.close()
-        return
-    assert h.info.skin_width == 4
+    nj = 8 if name.endswith('_w6') else 4  # six weights per vertex: eight pairs, pieces of up to eight joints (round 5)
+    assert h.info.skin_width == nj
     # pieces (what the batch-major vertex kernels walk): a partition of the sorted slots into runs of one part
     # with at most four skinning joints each, used parts first; and at least one padding slot behind the
     # vertices whenever those kernels can apply
     pcs = h.table('vertex_pieces').reshape(-1, 5)
     assert pcs[0, 0] == 0 and (pcs[1:, 0] == pcs[:-1, 0] + pcs[:-1, 1]).all()
     assert pcs[-1, 0] + pcs[-1, 1] == V
-    assert (pcs[:, 1] > 0).all() and (pcs[:, 4] >= 1).all() and (pcs[:, 4] <= 4).all()
+    assert (pcs[:, 1] > 0).all() and (pcs[:, 4] >= 1).all() and (pcs[:, 4] <= nj).all()
     for s, c, p, u, nq in pcs:
         assert (of.part[perm[s:s + c]] == p).all() and u == int(p in of.used_parts)
         joints = np.unique(np.nonzero(md.weights[perm[s:s + c]])[1])
         assert len(joints) == nq
     assert (np.diff(pcs[:, 3]) <= 0).all()  # used pieces first
-    check_share_tables(h, of, md, perm, V, plain=name != 'smpl_rnd')
+    check_share_tables(h, of, md, perm, V, plain=name != 'smpl_rnd', nj=nj)
     if V >= 1024:
         assert h.info.padded_vertices > V
     assert h.workspace_bytes(64) > 0
@@ -129,9 +125,10 @@ def test_general_models_create(lib, kind, model_root):
     hk.close()
 
 
-def check_share_tables(h, of, md, perm, V, plain=True):
+def check_share_tables(h, of, md, perm, V, plain=True, nj=4):
     """Every cell table deals its domain (all slots / used parts / adjustable parts) exactly once to its cells, in
-    cells of nearly equal cost, and its rows say where the partial sums go."""
+    cells of nearly equal cost, and its rows say where the partial sums go.  ``nj`` = 8: pieces of up to eight joints,
+    whose record is a PAIR of 12-int records (joints / local slots 4..7 in the second one, the other fields repeated)."""
     ncells = h.table('cell_counts')
     assert len(ncells) == 8 and all(n >= 8 and n & (n - 1) == 0 for n in ncells)  # powers of two; (coarse, fine) x 4 kinds
     assert all(ncells[4 + k] >= ncells[k] for k in range(4))
@@ -142,7 +139,10 @@ def check_share_tables(h, of, md, perm, V, plain=True):
         kind, fine = table % 4, table >= 4
         nc = int(ncells[table])
         start = h.share_table(table, 0)
-        rec = h.share_table(table, 1).reshape(-1, 12)
+        rec = h.share_table(table, 1).reshape(-1, 12 * (nj // 4))
+        if nj == 8:  # fold the pair into one logical record: count, joints[8], slots[8], first slot, row, tail
+            assert (rec[:, [0, 9, 10, 11]] == rec[:, [12, 21, 22, 23]]).all()
+            rec = np.concatenate([rec[:, 0:1], rec[:, 1:5], rec[:, 13:17], rec[:, 5:9], rec[:, 17:21], rec[:, 9:12]], 1)
         rows = h.share_table(table, 2)
         assert len(start) == nc + 1 and start[0] == 0 and start[-1] == len(rec) - 1
         assert (rec[-1] == 0).all()  # sentinel
@@ -152,7 +152,7 @@ def check_share_tables(h, of, md, perm, V, plain=True):
             cost, slots = 0, {}
             assert start[k + 1] > start[k]  # no empty cell
             for r in rec[start[k]:start[k + 1]]:
-                cnt, js, loc, s0, close, tail = r[0], r[1:5], r[5:9], r[9], r[10], r[11]
+                cnt, js, loc, s0, close, tail = r[0], r[1:1 + nj], r[1 + nj:1 + 2 * nj], r[-3], r[-2], r[-1]
                 assert cnt > 0
                 seen[s0:s0 + cnt] += 1
                 cost += cnt + (cnt & 1) + 3
@@ -173,9 +173,9 @@ def check_share_tables(h, of, md, perm, V, plain=True):
                         assert rows[row] == slot_part[s0]
                     row += 1
             last = rec[start[k + 1] - 1]
-            assert last[10] >= 0  # a cell always closes its last row: the rows do not depend on the multiplier
+            assert last[-2] >= 0  # a cell always closes its last row: the rows do not depend on the multiplier
             if kind == 0:
-                assert (last[11] >> 8) == k + 1 and all((r[11] >> 8) == 0 for r in rec[start[k]:start[k + 1] - 1])
+                assert (last[-1] >> 8) == k + 1 and all((r[-1] >> 8) == 0 for r in rec[start[k]:start[k + 1] - 1])
             costs.append(cost)
         assert (seen == domains[kind].astype(np.int32)).all()
         assert row == (len(rows) // 12 if kind == 0 else len(rows))
