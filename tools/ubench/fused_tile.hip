@@ -303,6 +303,112 @@ __global__ __launch_bounds__(64 * NWAVE) void k_fused(Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// SYMMETRIC form: every wave plays both roles in turn.  A workgroup of 8 waves = 256 instances = four 64-instance blocks;
+// per 32-slot tile: (A) every wave forms its 32 instances' three coordinate tiles (the library's GEMM loop, one barrier
+// per image) into an LDS tile [4 blocks][3][32][64] (98 KB); (B) wave w runs the residual step on 16 of the tile's slots
+// for block w / 2 (slots 16 (w & 1) ...), lane = instance; one more barrier closes the tile.  No MFMA / VALU overlap
+// inside a workgroup (the phases alternate), but in phase B all eight waves — two per SIMD, 256 registers each: the
+// occupancy of the library's eight-joint vertex kernels — do vertex work.  Targets of the next tile are requested before
+// phase A (they arrive under the products), vertex records one slot ahead.  grid (chunks of tiles, Mp / 256).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kSymTileFloats = 4 * 3 * 32 * 64;
+constexpr size_t kSymLds = 2 * (size_t)kImg + (size_t)kSymTileFloats * 4;  // 55296 + 98304
+template <bool WRITE_VPT, int ABL = 0>
+__global__ __launch_bounds__(512, 1) void k_fused_sym(Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ring = smem;
+  float* tile = reinterpret_cast<float*>(smem + 2 * kImg);
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Vp = a.Vp, ntile = Vp / 32;
+  const int t0 = blockIdx.x * a.tiles_per_wg, t1 = min(t0 + a.tiles_per_wg, ntile), nt = t1 - t0;
+  if (nt <= 0) return;
+  const int blk0 = blockIdx.y * 4;
+  // role A: instances (blk0 * 64 + wave * 32 ...), role B: block cblk, slots 16 h ... of every tile
+  const int pblk = wave >> 1, half = wave & 1;
+  const int blk = blk0 + pblk;
+  Features F;
+  load_features(a.A, blk0 * 64 + wave * 32 + l31, kg, F);
+  auto dma_image = [&](int u) {  // image of sub-step u (tile t0 + u / 3, coordinate u % 3) into ring slot u & 1
+    const char* src = a.img + (size_t)((u % 3) * ntile + t0 + u / 3) * kImg;
+    char* dst = ring + (u & 1) * kImg;
+#pragma unroll
+    for (int i = 0; i < (NDMA + 7) / 8; ++i) {
+      const int c = wave + 8 * i;
+      if (c < NDMA) lds_dma16(src + c * 1024, lane * 16, dst + c * 1024);
+    }
+  };
+  const float* tp = a.tT + (size_t)blk * 3 * Vp * 64 + lane;
+  const float* jdb = a.jdT + (size_t)blk * a.J * JROW * 64 + lane;
+  const size_t cstr = (size_t)Vp * 64;
+  Sums acc;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) acc.r1p[k] = mk2(0, 0);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { acc.m01[k] = mk2(0, 0); acc.m2[k] = 0.f; }
+  Piece jr;
+  float tg[16][3];  // targets of this wave's 16 slots of the CURRENT tile (requested before its phase A)
+  auto request_tile = [&](int t) {
+    const float* p = tp + (size_t)(t * 32 + half * 16) * 64;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) tg[i][c] = __builtin_nontemporal_load(p + (size_t)c * cstr + (size_t)i * 64);
+  };
+  Rec recA, recB;
+  dma_image(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int it = 0; it < nt; ++it) {
+    const int t = t0 + it;
+    if (!(ABL & 1)) request_tile(t);
+    // ---- phase A: three coordinate tiles of this wave's 32 instances ----
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+      const int u = it * 3 + c;
+      if (!(ABL & 2)) {
+        if (u + 1 < 3 * nt) dma_image(u + 1);
+        const f32x16 pr = tile_product(ring + (u & 1) * kImg, l31, kg, F);
+        float* dst = tile + (pblk * 3 + c) * 32 * 64;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[tile_col((r & 3) + 8 * (r >> 2) + 4 * kg, half * 32 + l31)] = pr[r];
+        if constexpr (WRITE_VPT) {
+          float* g = a.vpT + ((size_t)blk * 3 * Vp + (size_t)c * Vp + (size_t)t * 32) * 64 + half * 32 + l31;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(pr[r], g + (size_t)((r & 3) + 8 * (r >> 2) + 4 * kg) * 64);
+        }
+      }
+      // this wave's chunks of the next image have landed; the tile rows are written.  (The targets requested above are
+      // older than the DMA: a counted wait would have to keep them out — they have had a whole product to arrive.)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    // ---- phase B: 16 slots of block pblk ----
+    if (!(ABL & 1)) {
+      if (it % a.jperiod == 0) load_piece(jdb, (t * 2 + half) % a.J, a.J, jr);
+      const float* src = tile + pblk * 3 * 32 * 64;
+      load_rec(a.brec, t * 32 + half * 16, recA);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int slot = half * 16 + i;
+        const Rec rc = i & 1 ? recB : recA;
+        if (i + 1 < 16) {
+          asm volatile("" ::"s"(rc.cw[0]));
+          __builtin_amdgcn_sched_barrier(0);
+          if (i & 1) load_rec(a.brec, t * 32 + slot + 1, recA);
+          else load_rec(a.brec, t * 32 + slot + 1, recB);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const float x0 = src[tile_col(slot, lane)], x1 = src[32 * 64 + tile_col(slot, lane)], x2 = src[2 * 32 * 64 + tile_col(slot, lane)];
+        vertex_step(jr, rc, x0, x1, x2, tg[i][0], tg[i][1], tg[i][2], acc);
+      }
+    }
+    __builtin_amdgcn_s_barrier();  // the tile is consumed
+  }
+  store_sums(a.out, ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave, lane, acc);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // calibration: the same two loops UNFUSED.  k_gemm_only: 8 producer waves per workgroup (one CU each, as the library's
 // kernel), v_posed written instance-innermost with non-temporal stores.  k_residual_only: 4 waves per workgroup, a wave
 // = one 64-instance block x a run of slots, six non-temporal streams, two steps of requests in flight.
@@ -516,6 +622,30 @@ int main(int argc, char** argv) {
     printf("  %7.1f us\n", us);
     printf("ablation: consumers without the LDS reads of v_posed:");
     us = time_us([&] { hipLaunchKernelGGL((k_fused<false, false, 4>), dim3(nchunk, Mp / 128), dim3(64 * NWAVE), kLds, 0, a); });
+    printf("  %7.1f us\n", us);
+  }
+  {
+    CK(hipFuncSetAttribute((const void*)k_fused_sym<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSymLds));
+    CK(hipFuncSetAttribute((const void*)k_fused_sym<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSymLds));
+    CK(hipFuncSetAttribute((const void*)k_fused_sym<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSymLds));
+    CK(hipFuncSetAttribute((const void*)k_fused_sym<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSymLds));
+    CK(hipFuncGetAttributes(&fa, (const void*)k_fused_sym<false>));
+    printf("k_fused_sym: %d VGPRs, %zu B scratch\n", fa.numRegs, (size_t)fa.localSizeBytes);
+    for (int nchunk : {16, 24, 32, 48}) {
+      a.tiles_per_wg = (ntile + nchunk - 1) / nchunk; a.jperiod = 2;
+      printf("symmetric fused            chunks %2d (tiles / workgroup %2d):", nchunk, a.tiles_per_wg);
+      float us = time_us([&] { hipLaunchKernelGGL((k_fused_sym<false>), dim3(nchunk, Mp / 256), dim3(512), kSymLds, 0, a); });
+      printf("  %7.1f us\n", us);
+      printf("symmetric fused + vpT out  chunks %2d (tiles / workgroup %2d):", nchunk, a.tiles_per_wg);
+      us = time_us([&] { hipLaunchKernelGGL((k_fused_sym<true>), dim3(nchunk, Mp / 256), dim3(512), kSymLds, 0, a); });
+      printf("  %7.1f us\n", us);
+    }
+    a.tiles_per_wg = (ntile + 15) / 16;
+    printf("symmetric ablation: products alone (no vertex phase):");
+    float us = time_us([&] { hipLaunchKernelGGL((k_fused_sym<false, 1>), dim3(16, Mp / 256), dim3(512), kSymLds, 0, a); });
+    printf("  %7.1f us\n", us);
+    printf("symmetric ablation: vertex phase alone (no products):");
+    us = time_us([&] { hipLaunchKernelGGL((k_fused_sym<false, 2>), dim3(16, Mp / 256), dim3(512), kSymLds, 0, a); });
     printf("  %7.1f us\n", us);
   }
   {
