@@ -266,7 +266,7 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
   // A vertex count that is a multiple of the padding (vertex subsets of 1024, 2048, ...) gets one more
   // tile when those kernels apply: measured at B = 16384, 1024 vertices 4.58 -> 4.79 M fits/s, 2048
   // vertices 3.10 -> 3.69 M (512: the wave-per-instance kernels stay ahead, 5.85 vs 5.65 M).
-  if (t.Vp == V && (S == 10 || S == 11) && V >= 1024) t.Vp += kVertexPad;
+  if (t.Vp == V && bm_shape_count(S) && V >= 1024) t.Vp += kVertexPad;
   // models whose pose features do not fit the A-stationary GEMM (more than 24 joints): the tiled split-bf16 GEMM works on
   // 256-column tiles, so 3 Vp has to be a multiple of 256 (a vertex subset with an odd number of 128-vertex tiles would
   // otherwise fall back to the fp32 GEMM, three times slower)
@@ -371,6 +371,9 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
     max_nnz = std::max(max_nnz, nnz);
   }
   if (max_nnz > 8) general = true;
+  // (16 betas + the kid unknown + 5-8 weights per vertex: the one combination the wave-per-instance kernels are not
+  // built for — their LDS tiles would not fit; before round 5 such a model was refused)
+  if (max_nnz > 4 && S == 17) general = true;
   if (max_nnz > 64) {
     *unsupported = true;
     return "smplfit_create: more than 64 non-zero skinning weights per vertex";

@@ -28,6 +28,9 @@ constexpr int kGemmKPad = 16;    // posedirs K padded to the GEMM K step
 constexpr bool kGemm3 = SMPLFIT_GEMM_PRODUCTS == 3;
 constexpr int kJdStride = 52;    // floats per joint in the per-instance joint block (see sf_stages.h)
 
+// shape-unknown counts (betas + kid) the batch-major vertex kernels are instantiated for
+constexpr bool bm_shape_count(int S) { return S == 10 || S == 11 || S == 16 || S == 17; }
+
 enum PartType : int32_t { kPartNone = 0, kPartMulti = 1, kPartBone = 2, kPartLeaf = 3 };
 
 struct Segment {

@@ -317,7 +317,7 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w, bool fwd_
     for (size_t k = 0; k < t.shares.size(); ++k) {
       if ((int)k >= sf::kShareFine && B > sf::kFineMaxBatch) break;
       if ((int)k % sf::kShareKinds == sf::kShareResidual)
-        res_rows = std::max(res_rows, (size_t)t.shares[k].ncells * 16 + (size_t)t.shares[k].nrows * 3 * sf::kGroupJoints);
+        res_rows = std::max(res_rows, (size_t)t.shares[k].ncells * ((S + 3 + 3) / 4 * 4) + (size_t)t.shares[k].nrows * 3 * sf::kGroupJoints);
       else lbs_rows = std::max(lbs_rows, (size_t)t.shares[k].nrows);
     }
     // (the layout kernel's slab sums use ws.resP as scratch: 3 rows per slab)
@@ -459,7 +459,8 @@ bool bm_applies(const DevModel& d) {
   // Vp > V: the batch-major loops run their out-of-range steps on the first padding slot
   // (below ~1000 vertices the prologue of a wave outweighs its vertex work)
   // (KW == 8 since round 5: pieces of up to eight joints, two waves per SIMD — 5-8 skinning weights per vertex)
-  return use_bm() && (d.KW == 4 || d.KW == 8) && (d.S == 10 || d.S == 11) && d.bm_tables && d.V >= 1024 && d.Vp > d.V;
+  // (16 betas ± the kid unknown since round 5 as well: the same kernels at two waves per SIMD)
+  return use_bm() && (d.KW == 4 || d.KW == 8) && sf::bm_shape_count(d.S) && d.bm_tables && d.V >= 1024 && d.Vp > d.V;
 }
 
 // The batch-major residual kernel derives sum_v b_v from the per-joint moments: exact only when every vertex's
@@ -537,8 +538,12 @@ void launch_residual_bm_s(const smplfit_handle* h, const Workspace& ws, int B, h
                        st, d, sv, ws, B, Mp);
 }
 void launch_residual_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStream_t st, int which = 7) {
-  if (h->d.S == 11) launch_residual_bm_s<11>(h, ws, B, st, which);
-  else launch_residual_bm_s<10>(h, ws, B, st, which);
+  switch (h->d.S) {
+    case 11: launch_residual_bm_s<11>(h, ws, B, st, which); break;
+    case 16: launch_residual_bm_s<16>(h, ws, B, st, which); break;
+    case 17: launch_residual_bm_s<17>(h, ws, B, st, which); break;
+    default: launch_residual_bm_s<10>(h, ws, B, st, which);
+  }
 }
 
 // the vertex block of the normal equations accumulated per vertex on the batch-major path (S = 10): cell records +
@@ -577,7 +582,7 @@ void launch_lbs_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStrea
   const int Mp = (int)align_up((size_t)B, 128);
   const size_t lds = (size_t)tune().bm_lds_kb * 1024;
   const ShareView sv = share_view(h, write_v ? sf::kShareLbsAll : adj_only ? sf::kShareLbsAdj : sf::kShareLbsUsed, B);
-  if constexpr ((KW == 4 || KW == 8) && S <= 12) {  // what bm_applies admits (10 betas with or without the kid unknown)
+  if constexpr ((KW == 4 || KW == 8) && sf::bm_shape_count(S)) {  // what bm_applies admits (10 / 16 betas with or without the kid unknown)
     if (write_v) {
       // (write_all: every posed vertex — the alignment sums of a known-shape fit; else the slots the regressor reads)
       const int wa = write_all ? 1 : 0;
@@ -603,13 +608,22 @@ void launch_lbs_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStrea
 // conversion, BodyModel.forward, the mesh of a shape solve
 void launch_lbs_fwd_bm(const DevModel& d, const ShareView& sv, const Workspace& ws, int B, int Mp, hipStream_t st) {
   const dim3 grid = share_grid(sv, Mp);
+#define SF_FWD(S_, KW_) hipLaunchKernelGGL((k_lbs_partsum_bm<S_, KW_, true, true>), grid, dim3(64 * kBW), 0, st, d, sv, ws, B, Mp)
   if (d.KW == 8) {
-    if (d.S == 11) hipLaunchKernelGGL((k_lbs_partsum_bm<11, 8, true, true>), grid, dim3(64 * kBW), 0, st, d, sv, ws, B, Mp);
-    else hipLaunchKernelGGL((k_lbs_partsum_bm<10, 8, true, true>), grid, dim3(64 * kBW), 0, st, d, sv, ws, B, Mp);
+    switch (d.S) {
+      case 11: SF_FWD(11, 8); break;
+      case 16: SF_FWD(16, 8); break;
+      default: SF_FWD(10, 8);
+    }
   } else {
-    if (d.S == 11) hipLaunchKernelGGL((k_lbs_partsum_bm<11, 4, true, true>), grid, dim3(64 * kBW), 0, st, d, sv, ws, B, Mp);
-    else hipLaunchKernelGGL((k_lbs_partsum_bm<10, 4, true, true>), grid, dim3(64 * kBW), 0, st, d, sv, ws, B, Mp);
+    switch (d.S) {
+      case 11: SF_FWD(11, 4); break;
+      case 16: SF_FWD(16, 4); break;
+      case 17: SF_FWD(17, 4); break;
+      default: SF_FWD(10, 4);
+    }
   }
+#undef SF_FWD
 }
 
 template <int S, int KW>
@@ -1584,7 +1598,7 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
   }
   // stage images of the tiled split-bf16 GEMM (94 MB for SMPL-X): only for a model whose fits can take the
   // batch-major path (the only launches that read them; the structural part of bm_applies)
-  if ((h->t.KW == 4 || h->t.KW == 8) && (h->t.S == 10 || h->t.S == 11) && h->t.wsum_dev <= 1e-5f)
+  if ((h->t.KW == 4 || h->t.KW == 8) && sf::bm_shape_count(h->t.S) && h->t.wsum_dev <= 1e-5f)
     sf::build_tiled_gemm_images(h->t);
   const sf::HostTables& t = h->t;
   DevModel& d = h->d;
@@ -1705,7 +1719,7 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
           for (int r = 0; r < stb.nrows; ++r)
             for (int q = 0; q < sf::kGroupJoints; ++q)
               if (stb.row_joints[(size_t)r * sf::kGroupJoints + q] == j)
-                arows.push_back((int32_t)(stb.ncells * kResShareRec + r * kResRowRec + 3 * q));
+                arows.push_back((int32_t)(stb.ncells * res_share_rec(t.S) + r * kResRowRec + 3 * q));
           astart[j + 1] = (int32_t)arows.size();
         }
       } else {  // per part: its rows of ws.psumP

@@ -1115,8 +1115,51 @@ def test_cabi_error_paths(model_root, golden, dev):
     torch.cuda.synchronize()
 
 
+def test_sixteen_betas_full_size(model_root, dev, smplfit_env):
+    """16 betas at B = 4096 on the batch-major kernels (round 5; the wave-per-instance kernels before): against the
+    wave-per-instance result and fp64 oracle samples, run-to-run and slice-independent bit for bit; with the kid unknown."""
+    from smplfitter_amd import modelio
+    from smplfitter_amd.pt import BodyFitter, BodyModel
+
+    root = f'{model_root}/smpl_b16'
+    m = BodyModel('smpl', 'neutral', model_root=root, num_betas=16, device=dev)
+    B, J = 4096, m.num_joints
+    rs = np.random.RandomState(123)
+    fw = m(t((rs.randn(B, 3 * J) * 0.1).astype(np.float32), dev), t((rs.randn(B, 16) * 0.5).astype(np.float32), dev),
+           t(rs.randn(B, 3).astype(np.float32), dev))
+    g = torch.Generator(device='cpu').manual_seed(9)
+    tv = fw['vertices'] + (torch.randn(fw['vertices'].shape, generator=g) * 0.005).to(dev)
+    tj = fw['joints']
+    md = modelio.load_model('smpl', 'neutral', model_root=root, num_betas=16)
+    idx = np.array([0, 1, 2047, 2048, B - 1])
+    for kid in (False, True):
+        om64 = util.O.OracleModel(md, np.float64, 'smpl')
+        f = BodyFitter(m, enable_kid=kid)
+        keys = ['pose_rotvecs', 'shape_betas', 'trans'] + (['kid_factor'] if kid else [])
+        smplfit_env('SMPLFIT_BM', '1')
+        assert m.kernel_path(enable_kid=kid) == 'batch-major'
+        r = f.fit(tv, tj, num_iter=3, beta_regularizer=1.0, requested_keys=keys)
+        r2 = f.fit(tv, tj, num_iter=3, beta_regularizer=1.0, requested_keys=keys)
+        s = slice(B // 2 - 450, B // 2 + 450)
+        r3 = f.fit(tv[s], tj[s], num_iter=3, beta_regularizer=1.0, requested_keys=keys)
+        for k in keys:
+            assert torch.isfinite(r[k]).all() and torch.equal(r[k], r2[k]) and torch.equal(r[k][s], r3[k]), k
+        smplfit_env('SMPLFIT_BM', '0')
+        rw = f.fit(tv, tj, num_iter=3, beta_regularizer=1.0, requested_keys=keys)
+        smplfit_env('SMPLFIT_BM', '1')
+        kw = lambda d, i: dict(kid_factor=d['kid_factor'][i].cpu().numpy()) if kid else {}  # noqa: E731
+        va = om64.forward(*(r[k][idx].cpu().numpy() for k in ('pose_rotvecs', 'shape_betas', 'trans')), **kw(r, idx))['vertices']
+        vb = om64.forward(*(rw[k][idx].cpu().numpy() for k in ('pose_rotvecs', 'shape_betas', 'trans')), **kw(rw, idx))['vertices']
+        assert np.linalg.norm(va - vb, axis=-1).max() < 5e-5
+        ref = util.O.OracleFitter(om64, enable_kid=kid).fit(tv[idx].cpu().numpy(), tj[idx].cpu().numpy(), num_iter=3, beta_regularizer=1.0)
+        vr = om64.forward(ref['pose_rotvecs'], ref['shape_betas'], ref['trans'], **(dict(kid_factor=ref['kid_factor']) if kid else {}))['vertices']
+        err = np.linalg.norm(va - vr, axis=-1).max()
+        print(f'[b16] kid={kid} vs fp64 oracle {err:.2e}, batch-major vs wave-per-instance {np.linalg.norm(va - vb, axis=-1).max():.2e}')
+        assert err < 1e-4
+
+
 @pytest.mark.parametrize('nb', [6, 13])
-def test_num_betas_padding(nb, model_root, golden, dev):
+def test_num_betas_padding(nb, model_root, golden, dev, vertex_path):
     """BodyModel(num_betas=6 / 13): the library pads the shape unknowns to the 10 / 16 its kernels are built
     for and pins the padding to zero; shapes and results are the caller's count (reference fixture
     golden_nb_smpl.npz, tests/golden/make_golden_nb.py)."""
