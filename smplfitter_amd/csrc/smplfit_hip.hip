@@ -718,25 +718,35 @@ void launch_center_sort(const DevModel& d, const float* tv, const float* tj, con
 // loops over the unknowns and the skinning weights
 void set_max_lds_once(const void* fn) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
 int launch_gen_accum(const DevModel& d, const Workspace& ws, int B, bool weighted, hipStream_t st) {
-  const size_t lds = gen_accum_lds(d.S, d.KW);
+  const size_t lds = gen_accum_lds(d.J, d.S, d.KW);
   if (lds > 160 * 1024) return fail(SMPLFIT_ERR_UNSUPPORTED, "general path: too many shape unknowns for the accumulate kernel's LDS tile");
-  static std::once_flag once[16];
-  int dev_id = 0;
-  (void)hipGetDevice(&dev_id);
-  std::call_once(once[dev_id & 15], [] {
-    set_max_lds_once(reinterpret_cast<const void*>(&k_gen_accum<true, 8, 256>));
-    set_max_lds_once(reinterpret_cast<const void*>(&k_gen_accum<false, 8, 256>));
-    set_max_lds_once(reinterpret_cast<const void*>(&k_gen_accum<true, 32, 256>));
-    set_max_lds_once(reinterpret_cast<const void*>(&k_gen_accum<false, 32, 256>));
-  });
-  const bool wide = gen_tile_vertices(d.S) == 32, one_wave = gen_accum_threads(d.S) == 64;
-  if (one_wave) {  // (few unknowns: a wave per instance, 32 vertices per tile, LDS < 64 KB)
-    if (weighted) hipLaunchKernelGGL((k_gen_accum<true, 32, 64>), dim3(B), dim3(64), lds, st, d, ws, B);
-    else hipLaunchKernelGGL((k_gen_accum<false, 32, 64>), dim3(B), dim3(64), lds, st, d, ws, B);
-  } else if (weighted && wide) hipLaunchKernelGGL((k_gen_accum<true, 32, 256>), dim3(B), dim3(256), lds, st, d, ws, B);
-  else if (weighted) hipLaunchKernelGGL((k_gen_accum<true, 8, 256>), dim3(B), dim3(256), lds, st, d, ws, B);
-  else if (wide) hipLaunchKernelGGL((k_gen_accum<false, 32, 256>), dim3(B), dim3(256), lds, st, d, ws, B);
-  else hipLaunchKernelGGL((k_gen_accum<false, 8, 256>), dim3(B), dim3(256), lds, st, d, ws, B);
+  const bool stage = gen_accum_stage_joints(d.J, d.S, d.KW);
+  const int tv = gen_tile_vertices(d.S), nt = gen_accum_threads(d.S);
+  // (weighted, vertices per tile, threads, staged joint rows) -> instantiation
+#define SF_GEN(W_, TV_, NT_, ST_)                                                                              \
+  do {                                                                                                         \
+    static std::once_flag once_[16];                                                                           \
+    int dev_ = 0;                                                                                              \
+    (void)hipGetDevice(&dev_);                                                                                 \
+    std::call_once(once_[dev_ & 15], [] { set_max_lds_once(reinterpret_cast<const void*>(&k_gen_accum<W_, TV_, NT_, ST_>)); }); \
+    hipLaunchKernelGGL((k_gen_accum<W_, TV_, NT_, ST_>), dim3(B), dim3(NT_), lds, st, d, ws, B);               \
+  } while (0)
+#define SF_GEN_W(TV_, NT_, ST_)              \
+  do {                                       \
+    if (weighted) SF_GEN(true, TV_, NT_, ST_); \
+    else SF_GEN(false, TV_, NT_, ST_);       \
+  } while (0)
+#define SF_GEN_S(TV_, NT_)            \
+  do {                                \
+    if (stage) SF_GEN_W(TV_, NT_, true); \
+    else SF_GEN_W(TV_, NT_, false);   \
+  } while (0)
+  if (nt == 64) SF_GEN_S(32, 64);
+  else if (tv == 32) SF_GEN_S(32, 256);
+  else SF_GEN_S(8, 256);
+#undef SF_GEN_S
+#undef SF_GEN_W
+#undef SF_GEN
   return 0;
 }
 template <int MODE>
@@ -937,8 +947,8 @@ void launch_shape_solve(const DevModel& d, const Workspace& ws, int B, hipStream
                          kid_reg, pair_form, use_ref, mode, B - 1);
   } else {
     if (d.general)
-      hipLaunchKernelGGL((k_shape_solve<64, true>), dim3(B), dim3(64), solve_lds(d), st, d, ws, B, beta_reg, beta_reg2,
-                         kid_reg, pair_form, use_ref, mode, 0);
+      hipLaunchKernelGGL((k_shape_solve<64, true>), dim3(B), dim3(d.S > 64 ? 256 : 64), solve_lds(d), st, d, ws, B, beta_reg,
+                         beta_reg2, kid_reg, pair_form, use_ref, mode, 0);
     else
       hipLaunchKernelGGL(k_shape_solve<64>, dim3(B), dim3(64), solve_lds(d), st, d, ws, B, beta_reg, beta_reg2,
                          kid_reg, pair_form, use_ref, mode, 0);
