@@ -403,6 +403,69 @@ def test_workspace_guards(name, model_root, golden, dev):
             assert torch.equal(out['zero'][k], out['nan'][k]), k
 
 
+@pytest.mark.parametrize('kind,nb', [('smpl_w6', 10), ('smpl_b16', 16), ('smpl_b32', 32), ('smpl_w12', 10)])
+def test_workspace_guards_round5_paths(kind, nb, model_root, dev):
+    """The same guard / NaN-poison check on the kernels of round 5: pieces of eight joints (smpl_w6) and 16 betas (smpl_b16)
+    on the batch-major kernels, and the general path (smpl_b32, smpl_w12: k_gen_accum / k_gen_lbs, stage scratch in the
+    workspace) — default fit with a partial last block, the kid unknown, joints omitted, weights, a small batch, known
+    shape, known pose."""
+    from smplfitter_amd.pt import BodyFitter, BodyModel
+
+    m = BodyModel('smpl', 'neutral', model_root=f'{model_root}/{kind}', num_betas=nb, device=dev)
+    f, fk = BodyFitter(m), BodyFitter(m, enable_kid=True)
+    B = 300
+    rs = np.random.RandomState(3)
+    fw = m(t((rs.randn(B, 3 * m.num_joints) * 0.1).astype(np.float32), dev), t((rs.randn(B, nb) * 0.3).astype(np.float32), dev),
+           t(rs.randn(B, 3).astype(np.float32), dev))
+    tv, tj = fw['vertices'], fw['joints']
+    guard = 1 << 20
+    vw, jw = torch.rand(B, m.num_vertices, device=dev) + 0.5, torch.rand(B, m.num_joints, device=dev) + 0.5
+    cases = [
+        (f, False, dict(num_iter=2, beta_regularizer=1.0)),
+        (fk, False, dict(num_iter=2, beta_regularizer=1.0)),
+        (f, True, dict(num_iter=2, beta_regularizer=1.0)),
+        (f, False, dict(num_iter=2, vertex_weights=vw, joint_weights=jw)),
+        (f, False, dict(num_iter=2, beta_regularizer=1.0, _rows=37)),
+        (f, False, dict(_call='known_shape', num_iter=2)),
+        (f, False, dict(_call='known_pose')),
+    ]
+    zeros_pose, zeros_betas = torch.zeros(B, 3 * m.num_joints, device=dev), torch.zeros(B, nb, device=dev)
+    for fitter, no_joints, kw in cases:
+        kw = dict(kw)
+        call, rows = kw.pop('_call', 'fit'), kw.pop('_rows', B)
+        h = m._native(dev, kid=fitter.enable_kid)
+        n = h.workspace_bytes(rows)
+        buf = torch.empty(n + 2 * guard, dtype=torch.uint8, device=dev)
+        ws = buf[guard:guard + n]
+        out = {}
+        for fill in ('zero', 'nan'):
+            buf.fill_(0xA5)
+            if fill == 'zero':
+                ws.zero_()
+            else:
+                ws.view(torch.int32).fill_(0x7FC00000 | 0x1234)
+            kwr = {k: (v[:rows] if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
+            tjr = None if no_joints else tj[:rows]
+            if call == 'fit':
+                r = fitter.fit(tv[:rows], tjr, _workspace=ws, **kwr)
+            else:
+                keep = m._workspace
+                m._workspace = lambda h_, B_, device_, ws=ws: ws
+                try:
+                    if call == 'known_shape':
+                        r = fitter.fit_with_known_shape(zeros_betas[:rows], tv[:rows], tjr, **kwr)
+                    else:
+                        r = fitter.fit_with_known_pose(zeros_pose[:rows], tv[:rows], tjr, **kwr)
+                finally:
+                    m._workspace = keep
+            torch.cuda.synchronize()
+            assert bool((buf[:guard] == 0xA5).all()) and bool((buf[guard + n:] == 0xA5).all()), ('guard region written', kind, call)
+            out[fill] = {k: v.clone() for k, v in r.items()}
+            assert all(torch.isfinite(v).all() for v in r.values()), ('a result depends on uninitialised workspace', kind, call, kw.keys())
+        for k in out['zero']:
+            assert torch.equal(out['zero'][k], out['nan'][k]), (kind, call, k)
+
+
 @pytest.mark.usefixtures('two_chunks')
 @pytest.mark.parametrize('name,B,reps', [('smpl', 4096, 200), ('smplx', 2048, 60)])
 def test_neighbour_stress(name, B, reps, model_root, golden, dev):
