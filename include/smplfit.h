@@ -81,7 +81,8 @@ typedef struct smplfit_info {
   int32_t has_kid;
   int32_t padded_vertices;     /* Vp: vertices padded for the kernels                          */
   int32_t num_used_vertices;   /* vertices entering the part sums (pt/bodyfitter.py:109-114)   */
-  int32_t skin_width;          /* non-zero skinning weights kept per vertex (4 or 8)           */
+  int32_t skin_width;          /* (joint, weight) pairs kept per vertex: 4, 8, or — general path — the largest
+                                  count of non-zero weights of a vertex rounded up to 4 (up to 64)              */
   int32_t num_segments;        /* part-aligned 64-vertex tiles                                 */
   int32_t num_fk_levels;
   int32_t adj_last_level;
@@ -89,9 +90,11 @@ typedef struct smplfit_info {
   int32_t gemm_vgprs;          /* registers per lane of the split-bf16 GEMM kernels as built (0 without a device):
                                   they must own whole CUs (>= 256); below that the fp32-MFMA GEMM runs instead  */
   int32_t vertex_path;         /* which kernels the vertex passes of a default (unit-weight) fit run on:
-                                  SMPLFIT_PATH_BATCH_MAJOR (lane = instance, the fast path), SMPLFIT_PATH_WAVE
-                                  (one wave per instance: 16 betas, small subsets, non-normalised weights — about
-                                  0.4x the rate) or SMPLFIT_PATH_GENERAL (any number of betas / skinning weights) */
+                                  SMPLFIT_PATH_BATCH_MAJOR (lane = instance, the fast path: <= 8 weights per vertex,
+                                  10 or 16 betas with or without the kid unknown, >= 1024 vertices),
+                                  SMPLFIT_PATH_WAVE (one wave per instance: small subsets, non-normalised weights —
+                                  about 0.4x the rate) or SMPLFIT_PATH_GENERAL (any number of betas up to 1023 / of
+                                  skinning weights up to 64: run-time loops)                       */
   int32_t share_fallback;      /* bit k: cell table k (see smplfit_get_share_table) is a copy of a wider or coarser
                                   one because its own domain was too small for its cells; 0xffff: the model has
                                   no cell tables at all (SMPLFIT_PATH_WAVE)                                        */

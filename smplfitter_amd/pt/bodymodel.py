@@ -101,8 +101,8 @@ class BodyModel(nn.Module):
 
     def kernel_path(self, device: Optional[torch.device] = None, enable_kid: bool = False) -> str:
         """Which kernel family fits and forward passes of this model run on (``smplfit_info.vertex_path``):
-        ``'batch-major'`` (<= 8 skinning weights per vertex, <= 10 betas: the rates of the benchmark configurations),
-        ``'wave-per-instance'`` (11-16 betas, small vertex subsets: about 0.4 x the rate) or
+        ``'batch-major'`` (<= 8 skinning weights per vertex, <= 16 betas: the rates of the benchmark configurations),
+        ``'wave-per-instance'`` (small vertex subsets, non-normalised weights: about 0.4 x the rate) or
         ``'general'`` (any other ``num_betas`` — e.g. the default ``None``: every column of the file — or more than eight
         weights per vertex: run-time loops, a correctness path).  No counterpart in the reference."""
         device = self.v_template.device if device is None else torch.device(device)
