@@ -26,11 +26,17 @@ def trace_rows(d):
     return rows
 
 
+STEPS = 10  # timed fits of the traced bench command (tools/profile_round.sh: --steps 10 --warmup 3)
+
+
 def stats_csv(rows, path, head, chunks, warm=3):
     # steady state = the timed fits of the bench command: every fit ends with one k_refine_epilogue per chunk; the
     # window opens when the last warm-up fit has ended and closes with the last timed fit (bench.py's roofline leg —
     # repeated single-kernel launches — comes after it and is left out)
     ends = sorted(e for s, e, n in rows if short(n) == 'k_refine_epilogue')
+    # (bench.py's roofline leg launches k_refine_epilogue too — timing hook 10, round 5: only the refinements of the
+    # warm-up and timed fits count)
+    ends = ends[:(warm + STEPS) * chunks]
     t_lo, t_hi = ends[warm * chunks - 1], ends[-1]
     nfit = (len(ends) - warm * chunks) // chunks
     head += f'; statistics over the {nfit} timed fits (window between the {warm}rd and the last k_refine_epilogue)'
@@ -90,7 +96,8 @@ for k in sorted(set(fetch) | set(write)):
 rows = trace_rows(f'{src}/trace1')
 # only the fits themselves: bench.py's roofline leg (smplfit_time_kernel_f32: repeated single-kernel launches) and
 # its round-trip forward come after the last fit's epilogue
-last_fit_end = max((e for s, e, n in rows if short(n) == 'k_refine_epilogue'), default=None)
+fit_ends = sorted(e for s, e, n in rows if short(n) == 'k_refine_epilogue')[:3 + STEPS]  # (not the timing hook's launches)
+last_fit_end = fit_ends[-1] if fit_ends else None
 if last_fit_end is not None:
     rows = [r for r in rows if r[0] <= last_fit_end]
 cnt = collections.Counter(short(n) for s, e, n in rows)
