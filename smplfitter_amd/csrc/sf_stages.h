@@ -102,6 +102,7 @@ SF_HD JointScratch carve_joint_scratch(float* base, int J, int S, int kind) {
 }
 // solve stage scratch: (NE+1) + S*S + S + kSolveParts*S doubles, then S+3 floats
 constexpr int kSolveParts = 6;  // partial sums of the T' part of Jac^T b (see solve_stage)
+constexpr int kSolvePanel = 16;  // columns per panel of the blocked factorisation (general path)
 SF_HD int solve_scratch_floats(int S) {
   return 2 * (ne_size(S) + 1 + S * S + S + kSolveParts * S) + ((S + 3 + 3) / 4 * 4);
 }
@@ -480,7 +481,9 @@ SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const doubl
                        const float* gramj, const float* pext, const float* jd, const float* mb,
                        float beta_reg, float beta_reg2, float kid_reg, float* beta_out, float* trans_out,
                        float* rjoints_out, float* jb_out, const float* reg_ref = nullptr, int mode = 0,
-                       double* cen = nullptr, float* jbT_out = nullptr) {
+                       double* cen = nullptr, float* jbT_out = nullptr, double* panel = nullptr) {
+  // panel (general path: M lives in global memory): kSolvePanel * S + kSolvePanel doubles of LDS for the blocked
+  // factorisation below
   // jbT_out: the instance's column of the instance-innermost copy of jb ((J, 4) rows of 64 instances; element
   // (j, c) at jbT_out[(j * 4 + c) * 64]) read by the batch-major LBS kernel
   const int J = tb.J, S = tb.S, S1 = S + 1;
@@ -561,6 +564,59 @@ SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const doubl
   // NaN, which reaches every unknown — the failure signal of the Cholesky factorisation this replaces (sqrt of a
   // negative number; the reference ignores cholesky_ex's info and returns what it gets, :1083).
   double* rd = r2p;  // S: 1 / D_k
+  if (panel) {
+    // Many unknowns: M (S x S doubles) is in global memory, and the column-by-column form below reads and writes the
+    // whole trailing triangle once per column — S^3 / 6 x 16 bytes through L2 per instance (11.5 ms per launch at
+    // S = 300, B = 256: half of such a fit).  Blocked, right-looking: a panel of kSolvePanel columns is factorised in LDS
+    // (transposed: PT[q][r] = M[k0 + r][k0 + q], lanes along the rows), the forward substitution of its columns runs
+    // on the copy in LDS, and the trailing triangle takes ONE rank-kSolvePanel update per panel.  Same arithmetic
+    // (L_ik D_k left in M, 1 / D_k in rd; a non-positive pivot turns into NaN), the sums of a trailing entry grouped by panel.
+    double* PT = panel;                        // [kSolvePanel][S]
+    double* rdl = panel + kSolvePanel * S;     // [kSolvePanel] 1 / D of the panel's columns
+    for (int k0 = 0; k0 < S; k0 += kSolvePanel) {
+      const int wk = S - k0 < kSolvePanel ? S - k0 : kSolvePanel, rows = S - k0;
+      cx.sync();  // (the previous panel's trailing update is complete)
+      SF_FOR(idx, rows * wk) {
+        const int r = idx / wk, q = idx - r * wk;
+        PT[q * S + r] = r >= q ? M[(k0 + r) * S + k0 + q] : 0.0;
+      }
+      for (int q = 0; q < wk; ++q) {
+        cx.sync();
+        const double dk = PT[q * S + q];
+        const double rdk = dk > 0.0 ? 1.0 / dk : (dk - dk) / (dk - dk);
+        if (cx.lane == 0) {
+          rd[k0 + q] = rdk;
+          rdl[q] = rdk;
+        }
+        const double yq = x[k0 + q] * rdk;  // forward substitution with column k0 + q (x[k0 + q] is final: every earlier column has been applied)
+        const int nc = wk - 1 - q;          // the panel's columns to the right
+        SF_FOR(idx, (rows - q - 1) * (nc + 1)) {
+          const int r = q + 1 + idx / (nc + 1), c = idx % (nc + 1);
+          if (c == nc) {
+            x[k0 + r] -= PT[q * S + r] * yq;
+          } else {
+            const int q2 = q + 1 + c;
+            if (r >= q2) PT[q2 * S + r] -= (PT[q * S + r] * rdk) * PT[q * S + q2];
+          }
+        }
+      }
+      cx.sync();
+      SF_FOR(idx, rows * wk) {  // the factorised panel back to M (the back substitution reads it)
+        const int r = idx / wk, q = idx - r * wk;
+        if (r >= q) M[(k0 + r) * S + k0 + q] = PT[q * S + r];
+      }
+      const int t0 = k0 + wk, nt = S - t0;
+      SF_FOR(idx, nt * nt) {
+        const int a = idx / nt, b2 = idx - a * nt;
+        if (b2 <= a) {
+          double acc = M[(t0 + a) * S + t0 + b2];
+          for (int q = 0; q < wk; ++q) acc -= (PT[q * S + wk + a] * rdl[q]) * PT[q * S + wk + b2];
+          M[(t0 + a) * S + t0 + b2] = acc;
+        }
+      }
+    }
+    cx.sync();
+  } else {
   for (int k = 0; k < S; ++k) {
     cx.sync();
     const double dk = M[k * S + k];
@@ -580,6 +636,7 @@ SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const doubl
     cx.sync();
     const double yk = x[k] * rd[k];
     SF_FOR(i2, S) if (i2 > k) x[i2] -= M[i2 * S + k] * yk;
+  }
   }
   cx.sync();
   SF_FOR(i2, S) x[i2] *= rd[i2];  // z = D^-1 y

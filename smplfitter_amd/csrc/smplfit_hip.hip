@@ -396,6 +396,7 @@ struct Tuning {
   bool bm_known_shape = true;  // SMPLFIT_BM_KNOWN_SHAPE=0: fit_with_known_shape on the wave-per-instance kernels (A/B)
   bool bm_weighted = true; // SMPLFIT_BM_WEIGHTED=0: fits with vertex weights on the wave-per-instance kernels (A/B)
   int bm_slots = 4096;     // SMPLFIT_BM_SLOTS: resident waves a batch-major vertex pass is dealt for (share-count choice)
+  bool gen_mfma = true;    // SMPLFIT_GEN_MFMA=0: the general path's vertex block on the vector ALUs (k_gen_accum) instead of the matrix cores (A/B)
   int bm_lds_kb = 0;       // SMPLFIT_BM_LDS_KB: LDS request of the two batch-major vertex passes padded to this (54: three
                            // workgroups per CU instead of four, which leaves registers / LDS for another chunk's small kernels)
 };
@@ -423,6 +424,8 @@ Tuning read_tuning() {
   if (const char* e = env("SMPLFIT_FINE_B")) t.fine_b = std::min(std::max(atoi(e), 0), sf::kFineMaxBatch);
   if (const char* e = env("SMPLFIT_STAGE_HALF_B")) t.stage_half_b = std::max(atoi(e), 1);
   if (const char* e = env("SMPLFIT_BM_SLOTS")) t.bm_slots = std::min(std::max(atoi(e), 256), 16384);
+  if (const char* e = env("SMPLFIT_GEN_MFMA")) t.gen_mfma = e[0] != '0';
+  if (const char* e = env("SMPLFIT_GEN_NW")) g_gen2_large_nw = atoi(e) == 8 ? 8 : 16;
   if (const char* e = env("SMPLFIT_BM_LDS_KB")) t.bm_lds_kb = std::min(std::max(atoi(e), 0), 64);
   return t;
 }
@@ -717,7 +720,47 @@ void launch_center_sort(const DevModel& d, const float* tv, const float* tj, con
 // GENERAL path (kernels_gen.inc): the vertex block of the normal equations and the LBS / part-sum pass with run-time
 // loops over the unknowns and the skinning weights
 void set_max_lds_once(const void* fn) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
-int launch_gen_accum(const DevModel& d, const Workspace& ws, int B, bool weighted, hipStream_t st) {
+// the matrix-core form (k_gen_accum_mfma): (weighted, waves, blocks per wave, staged joint rows) -> instantiation
+int launch_gen_accum_mfma(const DevModel& d, const Workspace& ws, int B, bool weighted, float* vextra, const float* tj,
+                          const float* jw, hipStream_t st) {
+  const size_t lds = gen2_lds(d.J, d.S, d.KW);
+  if (lds > 160 * 1024) return fail(SMPLFIT_ERR_UNSUPPORTED, "general path: too many shape unknowns for the accumulate kernel's LDS tile");
+  const bool stage = gen2_stage_joints(d.J, d.S, d.KW);
+  const int nw = gen2_nw(d.S), nbw = gen2_nbw(d.S);
+  const dim3 grid(B, gen2_groups(d.S));
+#define SF_GEN2(W_, NW_, NBW_, ST_)                                                                                   \
+  do {                                                                                                                \
+    static std::once_flag once_[16];                                                                                  \
+    int dev_ = 0;                                                                                                     \
+    (void)hipGetDevice(&dev_);                                                                                        \
+    std::call_once(once_[dev_ & 15], [] { set_max_lds_once(reinterpret_cast<const void*>(&k_gen_accum_mfma<W_, NW_, NBW_, ST_>)); }); \
+    hipLaunchKernelGGL((k_gen_accum_mfma<W_, NW_, NBW_, ST_>), grid, dim3(64 * NW_), lds, st, d, ws, B, vextra, tj, jw); \
+  } while (0)
+#define SF_GEN2_W(NW_, NBW_, ST_)               \
+  do {                                          \
+    if (weighted) SF_GEN2(true, NW_, NBW_, ST_); \
+    else SF_GEN2(false, NW_, NBW_, ST_);        \
+  } while (0)
+#define SF_GEN2_S(NW_, NBW_)              \
+  do {                                    \
+    if (stage) SF_GEN2_W(NW_, NBW_, true); \
+    else SF_GEN2_W(NW_, NBW_, false);     \
+  } while (0)
+  if (nw == 4) SF_GEN2_S(4, 1);
+  else if (nbw == 1) SF_GEN2_S(16, 1);
+  else if (nw == 8) SF_GEN2_S(8, 8);
+  else SF_GEN2_S(16, 4);
+#undef SF_GEN2_S
+#undef SF_GEN2_W
+#undef SF_GEN2
+  return 0;
+}
+// (general path, matrix-core accumulate: the target joints enter as rows of the vertex block's kernel instead of the
+// joint block of k_joint_stage)
+bool gen_joint_rows(const DevModel& d) { return d.general && tune().gen_mfma; }
+int launch_gen_accum(const DevModel& d, const Workspace& ws, int B, bool weighted, hipStream_t st, const float* jrows_tj,
+                     const float* jrows_jw) {
+  if (tune().gen_mfma) return launch_gen_accum_mfma(d, ws, B, weighted, nullptr, jrows_tj, jrows_jw, st);
   const size_t lds = gen_accum_lds(d.J, d.S, d.KW);
   if (lds > 160 * 1024) return fail(SMPLFIT_ERR_UNSUPPORTED, "general path: too many shape unknowns for the accumulate kernel's LDS tile");
   const bool stage = gen_accum_stage_joints(d.J, d.S, d.KW);
@@ -759,8 +802,10 @@ void launch_gen_lbs(const DevModel& d, const Workspace& ws, int B, bool weighted
     hipLaunchKernelGGL((k_gen_lbs<MODE, false>), dim3(B), dim3(256), lds, st, d, ws, B, nb, beta, trans, kid, out);
 }
 // the vertex block / the LBS pass of the wave-per-instance path OR the general one, by model
-int launch_accum_any(const DevModel& d, const Workspace& ws, int B, bool weighted, hipStream_t st) {
-  if (d.general) return launch_gen_accum(d, ws, B, weighted, st);
+// jrows_tj / jrows_jw: the centred target joints (and their weights) when gen_joint_rows() moved the joint block here
+int launch_accum_any(const DevModel& d, const Workspace& ws, int B, bool weighted, hipStream_t st,
+                     const float* jrows_tj = nullptr, const float* jrows_jw = nullptr) {
+  if (d.general) return launch_gen_accum(d, ws, B, weighted, st, jrows_tj, jrows_jw);
 #define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, B, weighted, st)
   SF_DISPATCH_SKW(d, SF_CALL_ACCUM);
 #undef SF_CALL_ACCUM
@@ -892,7 +937,10 @@ int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, b
 size_t joint_lds(const DevModel& d, int kind = 0) {
   return (size_t)sf::joint_scratch_floats(d.J, d.general ? 0 : d.S, kind) * 4;
 }
-size_t solve_lds(const DevModel& d) { return d.general ? 0 : (size_t)sf::solve_scratch_floats(d.S) * 4; }
+// (general path: the stage's scratch is in global memory, LDS holds the panel of the blocked factorisation)
+size_t solve_lds(const DevModel& d) {
+  return d.general ? (size_t)(sf::kSolvePanel * d.S + sf::kSolvePanel) * 8 : (size_t)sf::solve_scratch_floats(d.S) * 4;
+}
 
 // The per-instance stages run two instances per wave (DevCtxHalf) when the model's joints fit 32 lanes and the batch
 // fills the chip either way (below ~2 workgroups per CU the one-instance form is the faster one: B = 256 0.416 vs
@@ -946,9 +994,14 @@ void launch_shape_solve(const DevModel& d, const Workspace& ws, int B, hipStream
       hipLaunchKernelGGL(k_shape_solve<64>, dim3(1), dim3(64), solve_lds(d), st, d, ws, B, beta_reg, beta_reg2,
                          kid_reg, pair_form, use_ref, mode, B - 1);
   } else {
-    if (d.general)
+    if (d.general) {
+      static std::once_flag once[16];
+      int dev_id = 0;
+      (void)hipGetDevice(&dev_id);
+      std::call_once(once[dev_id & 15], [] { set_max_lds_once(reinterpret_cast<const void*>(&k_shape_solve<64, true>)); });
       hipLaunchKernelGGL((k_shape_solve<64, true>), dim3(B), dim3(d.S > 64 ? 256 : 64), solve_lds(d), st, d, ws, B, beta_reg,
                          beta_reg2, kid_reg, pair_form, use_ref, mode, 0);
+    }
     else
       hipLaunchKernelGGL(k_shape_solve<64>, dim3(B), dim3(64), solve_lds(d), st, d, ws, B, beta_reg, beta_reg2,
                          kid_reg, pair_form, use_ref, mode, 0);
@@ -1096,7 +1149,8 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   JointStageArgs ja{};
   ja.tj = tj_rot;
   ja.jw = jw;
-  ja.joint_block = joints ? 1 : 0;
+  const bool gjr = gen_joint_rows(d) && joints;
+  ja.joint_block = (joints && !gjr) ? 1 : 0;
   ja.joint_block_weighted = eff_j ? 1 : 0;
   ja.vertex_sa_closed_form = (eff_v || d.general) ? 0 : 1;  // (the general accumulate sums SA itself)
   ja.do_prologue = o.rotations_only ? 0 : 1;
@@ -1166,7 +1220,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
       else launch_residual_bm(h, ws, B, st);
     } else {
       launch_gemm(d, ws, B, st);
-      if (int rc = launch_accum_any(d, ws, B, eff_v, st)) return rc;
+      if (int rc = launch_accum_any(d, ws, B, eff_v, st, gjr ? tj_rot : nullptr, gjr && eff_j ? jw : nullptr)) return rc;
     }
     // K4 stays its own launch: fused into the prologue of the LBS kernel (template flag SOLVE) its
     // ~40 serial barriers stall all four waves of the workgroup and the kernel ran 230 us longer
@@ -2132,7 +2186,8 @@ int smplfit_shape_solve_ex_f32(const smplfit_handle* h, const smplfit_shape_solv
   ja.jw = joint_weights;
   ja.fit_rotations = 0;
   ja.do_prologue = 1;
-  ja.joint_block = joints ? 1 : 0;
+  const bool gjr = gen_joint_rows(d) && joints;
+  ja.joint_block = (joints && !gjr) ? 1 : 0;
   ja.joint_block_weighted = eff_j ? 1 : 0;
   ja.vertex_sa_closed_form = (eff_v || d.general) ? 0 : 1;  // (the general accumulate sums SA itself)
   if (!joints) hipMemsetAsync(ws.tjreg, 0, (size_t)batch * d.J * 3 * 4, st);
@@ -2147,7 +2202,7 @@ int smplfit_shape_solve_ex_f32(const smplfit_handle* h, const smplfit_shape_solv
                        scaled);
   } else {
     launch_gemm(d, ws, batch, st);
-    if (int rc = launch_accum_any(d, ws, batch, eff_v, st)) return rc;
+    if (int rc = launch_accum_any(d, ws, batch, eff_v, st, gjr ? ja.tj : nullptr, gjr && eff_j ? joint_weights : nullptr)) return rc;
     rc = enqueue_solve(d, ws, batch, o, joints, eff_v, eff_j, joint_weights, (!eff_v && !d.general && use_pair_form()) ? 1 : 0,
                        use_ref, scaled, st);
   }
@@ -2378,7 +2433,7 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
           launch_residual_bm(h, ws, batch, st, 1);
           return 0;
         }
-        if (int rc = launch_accum_any(d, ws, batch, false, st)) return rc;
+        if (int rc = launch_accum_any(d, ws, batch, false, st, gen_joint_rows(d) ? ws.tjc : nullptr)) return rc;
         return 0;
       }
       case SMPLFIT_KERNEL_SHAPE_SOLVE:
@@ -2403,7 +2458,7 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
         ja.jw = nullptr;
         ja.fit_rotations = 1;
         ja.do_prologue = 1;
-        ja.joint_block = 1;
+        ja.joint_block = gen_joint_rows(d) ? 0 : 1;
         ja.joint_block_weighted = 0;
         ja.vertex_sa_closed_form = d.general ? 0 : 1;
         launch_joint_stage(d, ja, ws, batch, st);

@@ -1115,13 +1115,16 @@ def test_cabi_error_paths(model_root, golden, dev):
     torch.cuda.synchronize()
 
 
-def test_sixteen_betas_full_size(model_root, dev, smplfit_env):
-    """16 betas at B = 4096 on the batch-major kernels (round 5; the wave-per-instance kernels before): against the
-    wave-per-instance result and fp64 oracle samples, run-to-run and slice-independent bit for bit; with the kid unknown."""
+@pytest.mark.parametrize('kind', ['smpl_b16', 'smpl_w6_b16'])
+def test_sixteen_betas_full_size(model_root, dev, smplfit_env, kind):
+    """16 betas at B = 4096 on the batch-major kernels (round 5; the wave-per-instance kernels before), with four and with
+    six skinning weights per vertex: against the wave-per-instance result and fp64 oracle samples, run-to-run and
+    slice-independent bit for bit; with the kid unknown (17 unknowns: batch-major with four weights, the general path
+    with six)."""
     from smplfitter_amd import modelio
     from smplfitter_amd.pt import BodyFitter, BodyModel
 
-    root = f'{model_root}/smpl_b16'
+    root = f'{model_root}/{kind}'
     m = BodyModel('smpl', 'neutral', model_root=root, num_betas=16, device=dev)
     B, J = 4096, m.num_joints
     rs = np.random.RandomState(123)
@@ -1137,24 +1140,28 @@ def test_sixteen_betas_full_size(model_root, dev, smplfit_env):
         f = BodyFitter(m, enable_kid=kid)
         keys = ['pose_rotvecs', 'shape_betas', 'trans'] + (['kid_factor'] if kid else [])
         smplfit_env('SMPLFIT_BM', '1')
-        assert m.kernel_path(enable_kid=kid) == 'batch-major'
+        path = m.kernel_path(enable_kid=kid)
+        assert path == ('general' if kid and kind == 'smpl_w6_b16' else 'batch-major')
         r = f.fit(tv, tj, num_iter=3, beta_regularizer=1.0, requested_keys=keys)
         r2 = f.fit(tv, tj, num_iter=3, beta_regularizer=1.0, requested_keys=keys)
         s = slice(B // 2 - 450, B // 2 + 450)
         r3 = f.fit(tv[s], tj[s], num_iter=3, beta_regularizer=1.0, requested_keys=keys)
         for k in keys:
             assert torch.isfinite(r[k]).all() and torch.equal(r[k], r2[k]) and torch.equal(r[k][s], r3[k]), k
-        smplfit_env('SMPLFIT_BM', '0')
-        rw = f.fit(tv, tj, num_iter=3, beta_regularizer=1.0, requested_keys=keys)
-        smplfit_env('SMPLFIT_BM', '1')
         kw = lambda d, i: dict(kid_factor=d['kid_factor'][i].cpu().numpy()) if kid else {}  # noqa: E731
         va = om64.forward(*(r[k][idx].cpu().numpy() for k in ('pose_rotvecs', 'shape_betas', 'trans')), **kw(r, idx))['vertices']
-        vb = om64.forward(*(rw[k][idx].cpu().numpy() for k in ('pose_rotvecs', 'shape_betas', 'trans')), **kw(rw, idx))['vertices']
-        assert np.linalg.norm(va - vb, axis=-1).max() < 5e-5
+        dw = float('nan')
+        if path == 'batch-major':
+            smplfit_env('SMPLFIT_BM', '0')
+            rw = f.fit(tv, tj, num_iter=3, beta_regularizer=1.0, requested_keys=keys)
+            smplfit_env('SMPLFIT_BM', '1')
+            vb = om64.forward(*(rw[k][idx].cpu().numpy() for k in ('pose_rotvecs', 'shape_betas', 'trans')), **kw(rw, idx))['vertices']
+            dw = np.linalg.norm(va - vb, axis=-1).max()
+            assert dw < 5e-5
         ref = util.O.OracleFitter(om64, enable_kid=kid).fit(tv[idx].cpu().numpy(), tj[idx].cpu().numpy(), num_iter=3, beta_regularizer=1.0)
         vr = om64.forward(ref['pose_rotvecs'], ref['shape_betas'], ref['trans'], **(dict(kid_factor=ref['kid_factor']) if kid else {}))['vertices']
         err = np.linalg.norm(va - vr, axis=-1).max()
-        print(f'[b16] kid={kid} vs fp64 oracle {err:.2e}, batch-major vs wave-per-instance {np.linalg.norm(va - vb, axis=-1).max():.2e}')
+        print(f'[{kind}] kid={kid} {path}: vs fp64 oracle {err:.2e}, batch-major vs wave-per-instance {dw:.2e}')
         assert err < 1e-4
 
 

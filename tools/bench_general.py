@@ -8,7 +8,10 @@ from smplfitter_amd.pt import BodyFitter, BodyModel
 
 dev = torch.device('cuda:0')
 out = {}
-for kind, nb, B in (('smpl_b32', 32, 4096), ('smpl_w12', 10, 4096), ('smpl_b300', None, 256)):
+CASES = (('smpl_b32', 32, 4096), ('smpl_w12', 10, 4096), ('smpl_b300', None, 256))
+if len(sys.argv) > 1:  # python tools/bench_general.py smpl_b300 [batch]
+    CASES = tuple((k, nb, int(sys.argv[2]) if len(sys.argv) > 2 else B) for k, nb, B in CASES if k == sys.argv[1])
+for kind, nb, B in CASES:
     root = synth.ensure_model_root(kinds=(kind,))
     model = BodyModel('smpl', 'neutral', model_root=f'{root}/{kind}', num_betas=nb, device=dev)
     fitter = BodyFitter(model)

@@ -11,5 +11,5 @@ if [ "$1" = "build" ]; then
     -DSMPLFIT_STAGE_STAMPS ${STAMP_B:+-DSMPLFIT_STAMP_B=$STAMP_B} smplfit_hip.hip sf_tables.cpp -o $R/build_ab/lib_stamp.so
 else
   cd $R
-  SMPLFIT_LIB=build_ab/lib_stamp.so SMPLFIT_CHUNKS=1 timeout 200 python tools/ab_fit.py ${2:-smpl} ${3:-4096} < /dev/null 2>&1 | grep stamps | tail -4
+  SMPLFIT_LIB=build_ab/lib_stamp.so SMPLFIT_CHUNKS=1 timeout 200 python tools/ab_fit.py ${2:-smpl} ${3:-4096} < /dev/null 2>&1 | grep stamps | tail -${STAMP_LINES:-12}
 fi
