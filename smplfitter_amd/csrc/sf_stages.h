@@ -605,17 +605,37 @@ SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const doubl
         const int r = idx / wk, q = idx - r * wk;
         if (r >= q) M[(k0 + r) * S + k0 + q] = PT[q * S + r];
       }
+      // trailing triangle: a group of (up to) 64 lanes takes a ROW a — its 16 scaled panel values stay in registers — and
+      // the lanes the columns b2 <= a, four entries per lane requested together (one entry at a time every update
+      // waited for its own round trip to M: 2.4 of the stage's 3.0 ms at S = 300)
       const int t0 = k0 + wk, nt = S - t0;
-      SF_FOR(idx, nt * nt) {
-        const int a = idx / nt, b2 = idx - a * nt;
-        if (b2 <= a) {
-          double acc = M[(t0 + a) * S + t0 + b2];
-          for (int q = 0; q < wk; ++q) acc -= (PT[q * S + wk + a] * rdl[q]) * PT[q * S + wk + b2];
-          M[(t0 + a) * S + t0 + b2] = acc;
+      const int gl = cx.n < 64 ? cx.n : 64, ng = cx.n / gl, g = cx.lane / gl, l = cx.lane - g * gl;
+      for (int a = g; a < nt; a += ng) {
+        double la[kSolvePanel];
+        SF_UNROLL_FULL
+        for (int q = 0; q < kSolvePanel; ++q) la[q] = q < wk ? PT[q * S + wk + a] * rdl[q] : 0.0;
+        double* Mrow = M + (size_t)(t0 + a) * S + t0;
+        for (int b0 = l; b0 <= a; b0 += 4 * gl) {
+          double acc[4];
+          SF_UNROLL_FULL
+          for (int u = 0; u < 4; ++u) acc[u] = b0 + u * gl <= a ? Mrow[b0 + u * gl] : 0.0;
+          SF_UNROLL_FULL
+          for (int q = 0; q < kSolvePanel; ++q)
+            if (q < wk) {
+              SF_UNROLL_FULL
+              for (int u = 0; u < 4; ++u) {
+                const int b2 = b0 + u * gl <= a ? b0 + u * gl : 0;
+                acc[u] -= la[q] * PT[q * S + wk + b2];
+              }
+            }
+          SF_UNROLL_FULL
+          for (int u = 0; u < 4; ++u)
+            if (b0 + u * gl <= a) Mrow[b0 + u * gl] = acc[u];
         }
       }
     }
     cx.sync();
+    SF_STAMP(3);
   } else {
   for (int k = 0; k < S; ++k) {
     cx.sync();

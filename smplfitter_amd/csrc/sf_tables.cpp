@@ -421,7 +421,8 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
   t.vt.assign((size_t)3 * Vp, 0.f);
   t.dm.assign((size_t)3 * Vp, 0.f);
   t.sd.assign((size_t)3 * S * Vp, 0.f);
-  t.sdg.assign(general ? (size_t)Vp * 3 * S : 0, 0.f);  // general path: vertex-major (Vp, 3, S) rows
+  const int S4g = (S + 3) & ~3;  // (rows padded to a multiple of four floats: 16-byte loads of four unknowns)
+  t.sdg.assign(general ? (size_t)Vp * 3 * S4g : 0, 0.f);  // general path: vertex-major (Vp, 3, S4) rows
   t.widx.assign((size_t)(t.KW / 4) * Vp, 0u);
   t.wval.assign((size_t)t.KW * Vp, 0.f);
   t.pdT.assign((size_t)t.Kp * 3 * Vp, 0.f);
@@ -460,7 +461,7 @@ std::string build_tables(const smplfit_model_desc& d, HostTables& t, bool* unsup
       t.dm[(size_t)c * Vp + i] = wsum * acc;
       for (int s = 0; s < S; ++s) {
         t.sd[(size_t)(c * S + s) * Vp + i] = shapedirs[((size_t)v * 3 + c) * S + s];
-        if (general) t.sdg[((size_t)i * 3 + c) * S + s] = shapedirs[((size_t)v * 3 + c) * S + s];
+        if (general) t.sdg[((size_t)i * 3 + c) * S4g + s] = shapedirs[((size_t)v * 3 + c) * S + s];
       }
     }
   }

@@ -155,7 +155,7 @@ struct HostTables {
   std::vector<float> vt;        // (3,Vp)  v_template
   std::vector<float> dm;        // (3,Vp)  default mesh = forward(zero pose, zero betas)
   std::vector<float> sd;        // (3*S,Vp) shapedirs, row index c*S+s
-  std::vector<float> sdg;       // (Vp,3,S) the same vertex-major (general path only)
+  std::vector<float> sdg;       // (Vp,3,S4) the same vertex-major, rows padded to S4 = S rounded up to 4 (general path only)
   std::vector<Segment> segments_all;  // part-aligned tiles over [0, V)
   std::vector<uint32_t> widx;   // (KW/4, Vp) 4 joint ids per word, byte k = k-th pair
   std::vector<float> wval;      // (KW, Vp)

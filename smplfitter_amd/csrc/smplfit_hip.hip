@@ -79,7 +79,7 @@ struct DevModel {
   const int32_t *jn_start, *jn;               // neighbours of every joint (HostTables::jn)
   // GENERAL path (more than 16 betas / more than 8 skinning weights per vertex, kernels_gen.inc)
   int general;
-  const float* sdg;        // (Vp, 3, S) shapedirs, vertex-major
+  const float* sdg;        // (Vp, 3, S4) shapedirs, vertex-major, rows padded to a multiple of four
   const int32_t* segall;   // (nsegall, 3) part-aligned tiles over every slot
   int nsegall;
 };
@@ -425,7 +425,6 @@ Tuning read_tuning() {
   if (const char* e = env("SMPLFIT_STAGE_HALF_B")) t.stage_half_b = std::max(atoi(e), 1);
   if (const char* e = env("SMPLFIT_BM_SLOTS")) t.bm_slots = std::min(std::max(atoi(e), 256), 16384);
   if (const char* e = env("SMPLFIT_GEN_MFMA")) t.gen_mfma = e[0] != '0';
-  if (const char* e = env("SMPLFIT_GEN_NW")) g_gen2_large_nw = atoi(e) == 8 ? 8 : 16;
   if (const char* e = env("SMPLFIT_BM_LDS_KB")) t.bm_lds_kb = std::min(std::max(atoi(e), 0), 64);
   return t;
 }
@@ -748,8 +747,7 @@ int launch_gen_accum_mfma(const DevModel& d, const Workspace& ws, int B, bool we
   } while (0)
   if (nw == 4) SF_GEN2_S(4, 1);
   else if (nbw == 1) SF_GEN2_S(16, 1);
-  else if (nw == 8) SF_GEN2_S(8, 8);
-  else SF_GEN2_S(16, 4);
+  else SF_GEN2_S(8, 7);
 #undef SF_GEN2_S
 #undef SF_GEN2_W
 #undef SF_GEN2
@@ -999,7 +997,7 @@ void launch_shape_solve(const DevModel& d, const Workspace& ws, int B, hipStream
       int dev_id = 0;
       (void)hipGetDevice(&dev_id);
       std::call_once(once[dev_id & 15], [] { set_max_lds_once(reinterpret_cast<const void*>(&k_shape_solve<64, true>)); });
-      hipLaunchKernelGGL((k_shape_solve<64, true>), dim3(B), dim3(d.S > 64 ? 256 : 64), solve_lds(d), st, d, ws, B, beta_reg,
+      hipLaunchKernelGGL((k_shape_solve<64, true>), dim3(B), dim3(d.S > 128 ? 1024 : d.S > 64 ? 256 : 64), solve_lds(d), st, d, ws, B, beta_reg,
                          beta_reg2, kid_reg, pair_form, use_ref, mode, 0);
     }
     else
