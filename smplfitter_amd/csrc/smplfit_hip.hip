@@ -793,11 +793,23 @@ int launch_gen_accum(const DevModel& d, const Workspace& ws, int B, bool weighte
 template <int MODE>
 void launch_gen_lbs(const DevModel& d, const Workspace& ws, int B, bool weighted, int nb, const float* beta,
                     const float* trans, float* out, hipStream_t st, const float* kid = nullptr) {
-  const size_t lds = gen_lbs_lds(d.J, d.S);
-  if (weighted && MODE != 2)
-    hipLaunchKernelGGL((k_gen_lbs<MODE == 2 ? 0 : MODE, true>), dim3(B), dim3(256), lds, st, d, ws, B, nb, beta, trans, kid, out);
-  else
-    hipLaunchKernelGGL((k_gen_lbs<MODE, false>), dim3(B), dim3(256), lds, st, d, ws, B, nb, beta, trans, kid, out);
+  const size_t lds = gen_lbs_lds(d.J, d.S, B);
+  const int ni = gen_lbs_ni(d.S, B);
+#define SF_GLBS(M_, W_)                                                                                                   \
+  do {                                                                                                                    \
+    if (ni == 4) {                                                                                                        \
+      static std::once_flag once_[16];                                                                                    \
+      int dev_ = 0;                                                                                                       \
+      (void)hipGetDevice(&dev_);                                                                                          \
+      std::call_once(once_[dev_ & 15], [] { set_max_lds_once(reinterpret_cast<const void*>(&k_gen_lbs<M_, W_, 4>)); });   \
+      hipLaunchKernelGGL((k_gen_lbs<M_, W_, 4>), dim3((B + 3) / 4), dim3(256), lds, st, d, ws, B, nb, beta, trans, kid, out); \
+    } else {                                                                                                              \
+      hipLaunchKernelGGL((k_gen_lbs<M_, W_, 1>), dim3(B), dim3(256), lds, st, d, ws, B, nb, beta, trans, kid, out);       \
+    }                                                                                                                     \
+  } while (0)
+  if (weighted && MODE != 2) SF_GLBS((MODE == 2 ? 0 : MODE), true);
+  else SF_GLBS(MODE, false);
+#undef SF_GLBS
 }
 // the vertex block / the LBS pass of the wave-per-instance path OR the general one, by model
 // jrows_tj / jrows_jw: the centred target joints (and their weights) when gen_joint_rows() moved the joint block here
