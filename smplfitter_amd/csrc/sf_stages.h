@@ -457,6 +457,127 @@ SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
 }
 
 // ---------------------------------------------------------------------------------------------
+// Symmetric positive definite solve M x = b of the leading n x n block of M (lower triangle, row pitch ld), in place:
+// x holds b on entry and the solution on exit.  rd: n doubles of scratch (1 / D_k).  panel: null, or
+// kSolvePanel * n + kSolvePanel doubles of LDS for the blocked form (M in global memory: the general path).
+// ---------------------------------------------------------------------------------------------
+template <class Ctx>
+SF_HD void ldlt_solve(Ctx& cx, double* M, int ld, int n, double* x, double* rd, double* panel) {
+  // the reference's Cholesky solve (:1083-1084) as an in-place M = L D L^T (L unit lower: the same factorisation
+  // without the square roots; L_ik D_k is left in M[i][k], D_k on the diagonal) — ONE sync per column, every lane
+  // updating one entry of the trailing triangle, instead of three syncs and a lane-0 step per column — and
+  // column-oriented substitutions spread over the lanes instead of two serial triangular loops on lane 0
+  // (cycle stamps, S = 10: 26 k -> 8 k of the stage's 50 k cycles).  fp64 throughout, as before.
+  // (rd may alias scratch the caller has finished reading: the cx.sync() that opens the first column orders those
+  // reads before the first write of rd[0])
+  // A pivot D_k <= 0 (a Gramian that is not positive definite: a singular system with both regularisers at 0) becomes
+  // NaN, which reaches every unknown — the failure signal of the Cholesky factorisation this replaces (sqrt of a
+  // negative number; the reference ignores cholesky_ex's info and returns what it gets, :1083).
+  if (panel) {
+    // Many unknowns: M (S x S doubles) is in global memory, and the column-by-column form below reads and writes the
+    // whole trailing triangle once per column — S^3 / 6 x 16 bytes through L2 per instance (11.5 ms per launch at
+    // S = 300, B = 256: half of such a fit).  Blocked, right-looking: a panel of kSolvePanel columns is factorised in LDS
+    // (transposed: PT[q][r] = M[k0 + r][k0 + q], lanes along the rows), the forward substitution of its columns runs
+    // on the copy in LDS, and the trailing triangle takes ONE rank-kSolvePanel update per panel.  Same arithmetic
+    // (L_ik D_k left in M, 1 / D_k in rd; a non-positive pivot turns into NaN), the sums of a trailing entry grouped by panel.
+    double* PT = panel;                        // [kSolvePanel][n]
+    double* rdl = panel + kSolvePanel * n;     // [kSolvePanel] 1 / D of the panel's columns
+    for (int k0 = 0; k0 < n; k0 += kSolvePanel) {
+      const int wk = n - k0 < kSolvePanel ? n - k0 : kSolvePanel, rows = n - k0;
+      cx.sync();  // (the previous panel's trailing update is complete)
+      SF_FOR(idx, rows * wk) {
+        const int r = idx / wk, q = idx - r * wk;
+        PT[q * n + r] = r >= q ? M[(k0 + r) * ld + k0 + q] : 0.0;
+      }
+      for (int q = 0; q < wk; ++q) {
+        cx.sync();
+        const double dk = PT[q * n + q];
+        const double rdk = dk > 0.0 ? 1.0 / dk : (dk - dk) / (dk - dk);
+        if (cx.lane == 0) {
+          rd[k0 + q] = rdk;
+          rdl[q] = rdk;
+        }
+        const double yq = x[k0 + q] * rdk;  // forward substitution with column k0 + q (x[k0 + q] is final: every earlier column has been applied)
+        const int nc = wk - 1 - q;          // the panel's columns to the right
+        SF_FOR(idx, (rows - q - 1) * (nc + 1)) {
+          const int r = q + 1 + idx / (nc + 1), c = idx % (nc + 1);
+          if (c == nc) {
+            x[k0 + r] -= PT[q * n + r] * yq;
+          } else {
+            const int q2 = q + 1 + c;
+            if (r >= q2) PT[q2 * n + r] -= (PT[q * n + r] * rdk) * PT[q * n + q2];
+          }
+        }
+      }
+      cx.sync();
+      SF_FOR(idx, rows * wk) {  // the factorised panel back to M (the back substitution reads it)
+        const int r = idx / wk, q = idx - r * wk;
+        if (r >= q) M[(k0 + r) * ld + k0 + q] = PT[q * n + r];
+      }
+      // trailing triangle: a group of (up to) 64 lanes takes a ROW a — its 16 scaled panel values stay in registers — and
+      // the lanes the columns b2 <= a, four entries per lane requested together (one entry at a time every update
+      // waited for its own round trip to M: 2.4 of the stage's 3.0 ms at S = 300)
+      const int t0 = k0 + wk, nt = n - t0;
+      const int gl = cx.n < 64 ? cx.n : 64, ng = cx.n / gl, g = cx.lane / gl, l = cx.lane - g * gl;
+      for (int a = g; a < nt; a += ng) {
+        double la[kSolvePanel];
+        SF_UNROLL_FULL
+        for (int q = 0; q < kSolvePanel; ++q) la[q] = q < wk ? PT[q * n + wk + a] * rdl[q] : 0.0;
+        double* Mrow = M + (size_t)(t0 + a) * ld + t0;
+        for (int b0 = l; b0 <= a; b0 += 4 * gl) {
+          double acc[4];
+          SF_UNROLL_FULL
+          for (int u = 0; u < 4; ++u) acc[u] = b0 + u * gl <= a ? Mrow[b0 + u * gl] : 0.0;
+          SF_UNROLL_FULL
+          for (int q = 0; q < kSolvePanel; ++q)
+            if (q < wk) {
+              SF_UNROLL_FULL
+              for (int u = 0; u < 4; ++u) {
+                const int b2 = b0 + u * gl <= a ? b0 + u * gl : 0;
+                acc[u] -= la[q] * PT[q * n + wk + b2];
+              }
+            }
+          SF_UNROLL_FULL
+          for (int u = 0; u < 4; ++u)
+            if (b0 + u * gl <= a) Mrow[b0 + u * gl] = acc[u];
+        }
+      }
+    }
+    cx.sync();
+    SF_STAMP(3);
+  } else {
+  for (int k = 0; k < n; ++k) {
+    cx.sync();
+    const double dk = M[k * ld + k];
+    const double rdk = dk > 0.0 ? 1.0 / dk : (dk - dk) / (dk - dk);  // NaN for a non-positive pivot (0 / 0, also on a NaN pivot)
+    if (cx.lane == 0) rd[k] = rdk;
+    const int m = n - 1 - k;  // trailing rows i = k + 1 + a, columns j = k + 1 + b, b <= a
+    SF_FOR(idx, m * m) {
+      const int a = idx / m, b2 = idx % m;
+      if (b2 <= a) {
+        const int i2 = k + 1 + a, j2 = k + 1 + b2;
+        M[i2 * ld + j2] -= (M[i2 * ld + k] * rdk) * M[j2 * ld + k];
+      }
+    }
+  }
+  SF_STAMP(3);
+  for (int k = 0; k < n; ++k) {  // forward: y = L^-1 b
+    cx.sync();
+    const double yk = x[k] * rd[k];
+    SF_FOR(i2, n) if (i2 > k) x[i2] -= M[i2 * ld + k] * yk;
+  }
+  }
+  cx.sync();
+  SF_FOR(i2, n) x[i2] *= rd[i2];  // z = D^-1 y
+  for (int k = n - 1; k > 0; --k) {  // back: x = L^-T z
+    cx.sync();
+    const double xk = x[k];
+    SF_FOR(i2, k) x[i2] -= (M[k * ld + i2] * rd[i2]) * xk;
+  }
+  cx.sync();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Stage S — combine the vertex and joint blocks in fp64, centre, regularise, Cholesky-solve,
 // translation; joints and per-joint skinning translations at the solution.
 //   _fit_shape_gram, bodyfitter.py:1054-1101.
@@ -553,119 +674,9 @@ SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const doubl
     cx.sync();
   }
   SF_STAMP(2);
-  // the reference's Cholesky solve (:1083-1084) as an in-place M = L D L^T (L unit lower: the same factorisation
-  // without the square roots; L_ik D_k is left in M[i][k], D_k on the diagonal) — ONE sync per column, every lane
-  // updating one entry of the trailing triangle, instead of three syncs and a lane-0 step per column — and
-  // column-oriented substitutions spread over the lanes instead of two serial triangular loops on lane 0
-  // (cycle stamps, S = 10: 26 k -> 8 k of the stage's 50 k cycles).  fp64 throughout, as before.
-  // rd ALIASES r2p: the partial sums of r2 were read by the sum loop above, and the cx.sync() that opens the first
-  // column below is what orders those reads before the first write of rd[0].
-  // A pivot D_k <= 0 (a Gramian that is not positive definite: a singular system with both regularisers at 0) becomes
-  // NaN, which reaches every unknown — the failure signal of the Cholesky factorisation this replaces (sqrt of a
-  // negative number; the reference ignores cholesky_ex's info and returns what it gets, :1083).
-  double* rd = r2p;  // S: 1 / D_k
-  if (panel) {
-    // Many unknowns: M (S x S doubles) is in global memory, and the column-by-column form below reads and writes the
-    // whole trailing triangle once per column — S^3 / 6 x 16 bytes through L2 per instance (11.5 ms per launch at
-    // S = 300, B = 256: half of such a fit).  Blocked, right-looking: a panel of kSolvePanel columns is factorised in LDS
-    // (transposed: PT[q][r] = M[k0 + r][k0 + q], lanes along the rows), the forward substitution of its columns runs
-    // on the copy in LDS, and the trailing triangle takes ONE rank-kSolvePanel update per panel.  Same arithmetic
-    // (L_ik D_k left in M, 1 / D_k in rd; a non-positive pivot turns into NaN), the sums of a trailing entry grouped by panel.
-    double* PT = panel;                        // [kSolvePanel][S]
-    double* rdl = panel + kSolvePanel * S;     // [kSolvePanel] 1 / D of the panel's columns
-    for (int k0 = 0; k0 < S; k0 += kSolvePanel) {
-      const int wk = S - k0 < kSolvePanel ? S - k0 : kSolvePanel, rows = S - k0;
-      cx.sync();  // (the previous panel's trailing update is complete)
-      SF_FOR(idx, rows * wk) {
-        const int r = idx / wk, q = idx - r * wk;
-        PT[q * S + r] = r >= q ? M[(k0 + r) * S + k0 + q] : 0.0;
-      }
-      for (int q = 0; q < wk; ++q) {
-        cx.sync();
-        const double dk = PT[q * S + q];
-        const double rdk = dk > 0.0 ? 1.0 / dk : (dk - dk) / (dk - dk);
-        if (cx.lane == 0) {
-          rd[k0 + q] = rdk;
-          rdl[q] = rdk;
-        }
-        const double yq = x[k0 + q] * rdk;  // forward substitution with column k0 + q (x[k0 + q] is final: every earlier column has been applied)
-        const int nc = wk - 1 - q;          // the panel's columns to the right
-        SF_FOR(idx, (rows - q - 1) * (nc + 1)) {
-          const int r = q + 1 + idx / (nc + 1), c = idx % (nc + 1);
-          if (c == nc) {
-            x[k0 + r] -= PT[q * S + r] * yq;
-          } else {
-            const int q2 = q + 1 + c;
-            if (r >= q2) PT[q2 * S + r] -= (PT[q * S + r] * rdk) * PT[q * S + q2];
-          }
-        }
-      }
-      cx.sync();
-      SF_FOR(idx, rows * wk) {  // the factorised panel back to M (the back substitution reads it)
-        const int r = idx / wk, q = idx - r * wk;
-        if (r >= q) M[(k0 + r) * S + k0 + q] = PT[q * S + r];
-      }
-      // trailing triangle: a group of (up to) 64 lanes takes a ROW a — its 16 scaled panel values stay in registers — and
-      // the lanes the columns b2 <= a, four entries per lane requested together (one entry at a time every update
-      // waited for its own round trip to M: 2.4 of the stage's 3.0 ms at S = 300)
-      const int t0 = k0 + wk, nt = S - t0;
-      const int gl = cx.n < 64 ? cx.n : 64, ng = cx.n / gl, g = cx.lane / gl, l = cx.lane - g * gl;
-      for (int a = g; a < nt; a += ng) {
-        double la[kSolvePanel];
-        SF_UNROLL_FULL
-        for (int q = 0; q < kSolvePanel; ++q) la[q] = q < wk ? PT[q * S + wk + a] * rdl[q] : 0.0;
-        double* Mrow = M + (size_t)(t0 + a) * S + t0;
-        for (int b0 = l; b0 <= a; b0 += 4 * gl) {
-          double acc[4];
-          SF_UNROLL_FULL
-          for (int u = 0; u < 4; ++u) acc[u] = b0 + u * gl <= a ? Mrow[b0 + u * gl] : 0.0;
-          SF_UNROLL_FULL
-          for (int q = 0; q < kSolvePanel; ++q)
-            if (q < wk) {
-              SF_UNROLL_FULL
-              for (int u = 0; u < 4; ++u) {
-                const int b2 = b0 + u * gl <= a ? b0 + u * gl : 0;
-                acc[u] -= la[q] * PT[q * S + wk + b2];
-              }
-            }
-          SF_UNROLL_FULL
-          for (int u = 0; u < 4; ++u)
-            if (b0 + u * gl <= a) Mrow[b0 + u * gl] = acc[u];
-        }
-      }
-    }
-    cx.sync();
-    SF_STAMP(3);
-  } else {
-  for (int k = 0; k < S; ++k) {
-    cx.sync();
-    const double dk = M[k * S + k];
-    const double rdk = dk > 0.0 ? 1.0 / dk : (dk - dk) / (dk - dk);  // NaN for a non-positive pivot (0 / 0, also on a NaN pivot)
-    if (cx.lane == 0) rd[k] = rdk;
-    const int m = S - 1 - k;  // trailing rows i = k + 1 + a, columns j = k + 1 + b, b <= a
-    SF_FOR(idx, m * m) {
-      const int a = idx / m, b2 = idx % m;
-      if (b2 <= a) {
-        const int i2 = k + 1 + a, j2 = k + 1 + b2;
-        M[i2 * S + j2] -= (M[i2 * S + k] * rdk) * M[j2 * S + k];
-      }
-    }
-  }
-  SF_STAMP(3);
-  for (int k = 0; k < S; ++k) {  // forward: y = L^-1 b
-    cx.sync();
-    const double yk = x[k] * rd[k];
-    SF_FOR(i2, S) if (i2 > k) x[i2] -= M[i2 * S + k] * yk;
-  }
-  }
-  cx.sync();
-  SF_FOR(i2, S) x[i2] *= rd[i2];  // z = D^-1 y
-  for (int k = S - 1; k > 0; --k) {  // back: x = L^-T z
-    cx.sync();
-    const double xk = x[k];
-    SF_FOR(i2, k) x[i2] -= (M[k * S + i2] * rd[i2]) * xk;
-  }
-  cx.sync();
+  // rd ALIASES r2p: the partial sums of r2 were read by the sum loop above, and the cx.sync() that opens the
+  // factorisation is what orders those reads before the first write of rd[0].
+  ldlt_solve(cx, M, S, S, x, r2p, panel);  // (rd ALIASES r2p: see below)
   SF_STAMP(4);
   // translation (:1086-1088) and outputs, cast to fp32 (:1088-1089)
   float* betaf = aux;       // S
@@ -706,7 +717,7 @@ SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const doubl
 // (computed here from P and the target joints):
 //   scale_target (mode 1), c = -t:      g = -u,  h = tt,  q = -tb,  Sc = -St
 //   scale_fit    (mode 2), c = t - b:   g = u - r,  h = tt - 2 tb + bb,  q = tb - bb,  Sc = St - Sb
-// scratch: doubles [NE+1 | (S+1)^2 | S+1 | S | 8] then floats.  Outputs: beta_out (S, UNDIVIDED — what the
+// scratch: doubles [NE+1 | (S+1)^2 | S+1 | S | 8 | S+1] then floats.  Outputs: beta_out (S, UNDIVIDED — what the
 // reference returns and hands to the refinement, :1277-1283), beta_eval (S, divided by the scale for
 // scale_fit: the shape the mesh is evaluated at, :1289-1293), trans, scale, joints, jb.
 // share_beta with a scale unknown (lstsq_partial_share with n_shared = S, pt/lstsq.py:50-90: the shape
@@ -718,8 +729,15 @@ SF_HD void solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, const doubl
 // matrix with weight lambda and right-hand side lambda * reference (:52-61), so reg_ref enters with
 // lambda^2 — restated as the reference computes it.
 // ---------------------------------------------------------------------------------------------
+// (general path: one scratch slot per instance serves both solve stages)
+SF_HD int gen_solve_scratch_floats(int S);
 SF_HD int scaled_solve_scratch_floats(int S) {
-  return 2 * (ne_size(S) + 1 + (S + 1) * (S + 1) + (S + 1) + S + 8) + ((S + 8) / 4 * 4);
+  return 2 * (ne_size(S) + 1 + (S + 1) * (S + 1) + (S + 1) + S + 8 + (S + 1)) + ((S + 8) / 4 * 4);
+}
+
+SF_HD int gen_solve_scratch_floats(int S) {
+  const int a = solve_scratch_floats(S), b = scaled_solve_scratch_floats(S);
+  return a > b ? a : b;
 }
 
 template <class Ctx>
@@ -729,7 +747,11 @@ SF_HD void scaled_solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, cons
                               int mode, float beta_reg, float beta_reg2, float kid_reg, float scale_reg,
                               const float* reg_ref, float* beta_out, float* beta_eval, float* trans_out,
                               float* scale_out, float* rjoints_out, float* jb_out, int share = 0,
-                              double* cen = nullptr) {
+                              double* cen = nullptr, double* panel = nullptr, const double* vextra_d = nullptr) {
+  // vextra_d: the vertices' extra sums as doubles (general path: k_gen_accum_mfma) instead of vextra
+  // panel (general path: the scratch, M included, is in global memory): LDS for ldlt_solve's blocked form — the
+  // (S + 1)-unknown system is then solved as L D L^T with column-oriented substitutions instead of the Cholesky
+  // factorisation and the two serial triangular loops on lane 0 below (S^2 dependent round trips to global memory)
   const int J = tb.J, S = tb.S, S1 = S + 1, N = S + 1;
   const int NG = ne_ng(S), NE = ne_size(S);
   double* sum = reinterpret_cast<double*>(scratch);  // NE+1
@@ -737,7 +759,8 @@ SF_HD void scaled_solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, cons
   double* x = M + N * N;                             // N
   double* u = x + N;                                 // S: sum w Jac^T t, vertices + joints
   double* ex = u + S;                                // [tt, tb, bb, St(3)] vertices + joints
-  float* aux = reinterpret_cast<float*>(ex + 8);     // S+4 floats
+  double* rdv = ex + 8;                              // N: 1 / D_k of ldlt_solve (panel form)
+  float* aux = reinterpret_cast<float*>(rdv + N);    // S+4 floats
   SF_FOR(e, NE + 1) {
     double v = gramv[e] + (double)gramj[e];
     if (mb && e >= NG && e < NG + S) {  // pair-Gram form of the vertex block (see stage S)
@@ -751,7 +774,7 @@ SF_HD void scaled_solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, cons
   }
   // the extra sums: vertices + joints
   SF_FOR(i, S + kScaleExtras) {
-    double v = (double)vextra[i];
+    double v = vextra_d ? vextra_d[i] : (double)vextra[i];
     if (joint_block) {
       float acc = 0.f;
       for (int j = 0; j < J; ++j) {
@@ -830,35 +853,48 @@ SF_HD void scaled_solve_stage(Ctx& cx, const JointTabs& tb, float* scratch, cons
     n = S;
     cx.sync();
   }
-  for (int k = 0; k < n; ++k) {  // Cholesky, column by column
-    if (cx.lane == 0) M[k * N + k] = sqrt(M[k * N + k]);
+  if (panel) {
+    ldlt_solve(cx, M, N, n, x, rdv, panel);
+    if (share == 2) {  // this instance's scale from the shared shape (row S of M and x[S] are untouched: n == S)
+      cx.sync();
+      if (cx.lane == 0) {
+        double v = x[S];
+        for (int j = 0; j < S; ++j) v -= M[S * N + j] * x[j];
+        x[S] = v / M[S * N + S];
+      }
+    }
     cx.sync();
-    SF_FOR(i, n) if (i > k) M[i * N + k] /= M[k * N + k];
-    cx.sync();
-    SF_FOR(idx, n * n) {
-      const int i = idx / n, j = idx % n;
-      if (j > k && i >= j) M[i * N + j] -= M[i * N + k] * M[j * N + k];
+  } else {
+    for (int k = 0; k < n; ++k) {  // Cholesky, column by column
+      if (cx.lane == 0) M[k * N + k] = sqrt(M[k * N + k]);
+      cx.sync();
+      SF_FOR(i, n) if (i > k) M[i * N + k] /= M[k * N + k];
+      cx.sync();
+      SF_FOR(idx, n * n) {
+        const int i = idx / n, j = idx % n;
+        if (j > k && i >= j) M[i * N + j] -= M[i * N + k] * M[j * N + k];
+      }
+      cx.sync();
+    }
+    if (cx.lane == 0) {
+      for (int i = 0; i < n; ++i) {
+        double v = x[i];
+        for (int k = 0; k < i; ++k) v -= M[i * N + k] * x[k];
+        x[i] = v / M[i * N + i];
+      }
+      for (int i = n - 1; i >= 0; --i) {
+        double v = x[i];
+        for (int k = i + 1; k < n; ++k) v -= M[k * N + i] * x[k];
+        x[i] = v / M[i * N + i];
+      }
+      if (share == 2) {  // this instance's scale from the shared shape
+        double v = x[S];
+        for (int j = 0; j < S; ++j) v -= M[S * N + j] * x[j];
+        x[S] = v / M[S * N + S];
+      }
     }
     cx.sync();
   }
-  if (cx.lane == 0) {
-    for (int i = 0; i < n; ++i) {
-      double v = x[i];
-      for (int k = 0; k < i; ++k) v -= M[i * N + k] * x[k];
-      x[i] = v / M[i * N + i];
-    }
-    for (int i = n - 1; i >= 0; --i) {
-      double v = x[i];
-      for (int k = i + 1; k < n; ++k) v -= M[k * N + i] * x[k];
-      x[i] = v / M[i * N + i];
-    }
-    if (share == 2) {  // this instance's scale from the shared shape
-      double v = x[S];
-      for (int j = 0; j < S; ++j) v -= M[S * N + j] * x[j];
-      x[S] = v / M[S * N + S];
-    }
-  }
-  cx.sync();
   float* betaf = aux;            // S: the shape the mesh is evaluated at
   float* transf = aux + S;       // 3
   const float scale = (float)x[S] + 1.0f;  // new_scale_corr (:1286)

@@ -226,8 +226,10 @@ struct Workspace {
   float* mbj;      // (B,J,3) per-joint residual moments (pair-Gram form)
   float* scale;    // (B) scale_corr of the known-shape fit
   float* regref;   // (B,S) ridge reference of the warm-started fit
-  double* cen;     // (B, S*S+S) centred regularised systems of a share_beta fit; row B = their sum
+  double* cen;     // (B, S*S+S) centred regularised systems of a share_beta fit (general path: one chunk of share_chunk() rows)
   double* cenP;    // (ceil(B/64), S*S+S) partial sums of the rows above (k_share_partial)
+  double* censum;  // (S*S+S) their sum (row B of cen; general path: a row of its own)
+  double* gvex;    // (B, S+6) general path: extra sums of the scaled solve (target column of k_gen_accum_mfma)
   float* vextra;   // (B,32) extra vertex sums of the scaled solve (scale_extras_vertex)
   float* beta_out; // (B,S) undivided shape of the scaled solve (ws.beta holds the evaluated one)
   float* tjs;      // (B,J,3) target joints times the scale (scale_target refinement)
@@ -242,7 +244,7 @@ struct Workspace {
   float* accP;     // (cells, NE+1, Mp) cell records of the weighted accumulate (k_accum_w_bm)
   // general path: the S-sized scratch of the per-instance stages lives here instead of LDS
   float* gT;       // (B,J,3,S+1) T = P - G J_ext of the joint stage (its P is ws.pext)
-  float* gsolve;   // (B, solve_scratch_floats(S)) the S x S system of stage S
+  float* gsolve;   // (B, gen_solve_scratch_floats(S)) the scratch of stage S / S' (the S x S system)
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -264,6 +266,9 @@ constexpr int kAccExtrasHost = 16;  // (= kAccExtras of kernels_bm.inc: the extr
 
 // fwd_only: the slice a batch-major forward of this model needs (the input side of a fused conversion, see
 // smplfit_convert_f32): pose features, joint rows, shape / translation and the instance-innermost v_posed buffer.
+// general path: instances per chunk of a share_beta solve (the workspace reserves their S^2 + S doubles)
+inline int share_chunk(int B) { return std::min((B + 63) / 64 * 64, 256); }
+
 size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w, bool fwd_only = false) {
   const size_t Mp = align_up((size_t)B, 128);
   const size_t Vp = t.Vp, J = t.J, S = t.S, NE1 = t.ne() + 1;
@@ -301,9 +306,12 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w, bool fwd_
   ws.mbj = (float*)take((size_t)B * J * 3 * 4);
   ws.scale = (float*)take((size_t)B * 4);
   ws.regref = (float*)take((size_t)B * S * 4, true);
-  // (the general path has no share_beta solve: its (S^2 + S) rows per instance are not reserved)
-  ws.cen = (double*)take(t.general ? 0 : ((size_t)B + 1) * (S * S + S) * 8);
-  ws.cenP = (double*)take(t.general ? 0 : ((size_t)B + 63) / 64 * (S * S + S) * 8);
+  // (general path: (S^2 + S) doubles per instance — 0.7 MB at S = 300 — are reserved for ONE chunk of the batch; a
+  // share_beta solve writes and sums the instances' systems chunk by chunk, in the order of the unchunked sum)
+  ws.cen = (double*)take((t.general ? (size_t)share_chunk(B) : (size_t)B + 1) * (S * S + S) * 8);
+  ws.cenP = (double*)take(((size_t)B + 63) / 64 * (S * S + S) * 8);
+  ws.censum = t.general ? (double*)take((S * S + S) * 8) : (ws.cen ? ws.cen + (size_t)B * (S * S + S) : nullptr);
+  ws.gvex = (double*)take(t.general ? (size_t)B * (S + sf::kScaleExtras) * 8 : 0);
   ws.vextra = (float*)take((size_t)B * 32 * 4);
   ws.beta_out = (float*)take((size_t)B * S * 4);
   ws.tjs = (float*)take((size_t)B * J * 3 * 4);
@@ -337,7 +345,7 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w, bool fwd_
   }
   ws.jdT = (float*)take(t.general ? 0 : Mp * align_up((size_t)J * sf::jd_stride(S), 64) * 4, true);
   ws.gT = (float*)take(t.general ? (size_t)B * J * 3 * (S + 1) * 4 : 0, true);
-  ws.gsolve = (float*)take(t.general ? (size_t)B * align_up((size_t)sf::solve_scratch_floats((int)S), 4) * 4 : 0);
+  ws.gsolve = (float*)take(t.general ? (size_t)B * align_up((size_t)sf::gen_solve_scratch_floats((int)S), 4) * 4 : 0);
   if (w) *w = ws;
   return off;
 }
@@ -396,6 +404,7 @@ struct Tuning {
   bool bm_known_shape = true;  // SMPLFIT_BM_KNOWN_SHAPE=0: fit_with_known_shape on the wave-per-instance kernels (A/B)
   bool bm_weighted = true; // SMPLFIT_BM_WEIGHTED=0: fits with vertex weights on the wave-per-instance kernels (A/B)
   int bm_slots = 4096;     // SMPLFIT_BM_SLOTS: resident waves a batch-major vertex pass is dealt for (share-count choice)
+  int gen_flush = 0;       // SMPLFIT_GEN_FLUSH: vertices between two fp64 additions of the general accumulate kernel's fp32 sums (0: 2048; a scaled iteration: every blend pass)
   bool gen_mfma = true;    // SMPLFIT_GEN_MFMA=0: the general path's vertex block on the vector ALUs (k_gen_accum) instead of the matrix cores (A/B)
   int bm_lds_kb = 0;       // SMPLFIT_BM_LDS_KB: LDS request of the two batch-major vertex passes padded to this (54: three
                            // workgroups per CU instead of four, which leaves registers / LDS for another chunk's small kernels)
@@ -425,6 +434,7 @@ Tuning read_tuning() {
   if (const char* e = env("SMPLFIT_STAGE_HALF_B")) t.stage_half_b = std::max(atoi(e), 1);
   if (const char* e = env("SMPLFIT_BM_SLOTS")) t.bm_slots = std::min(std::max(atoi(e), 256), 16384);
   if (const char* e = env("SMPLFIT_GEN_MFMA")) t.gen_mfma = e[0] != '0';
+  if (const char* e = env("SMPLFIT_GEN_FLUSH")) t.gen_flush = std::max(atoi(e), 0);
   if (const char* e = env("SMPLFIT_BM_LDS_KB")) t.bm_lds_kb = std::min(std::max(atoi(e), 0), 64);
   return t;
 }
@@ -720,20 +730,23 @@ void launch_center_sort(const DevModel& d, const float* tv, const float* tj, con
 // loops over the unknowns and the skinning weights
 void set_max_lds_once(const void* fn) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
 // the matrix-core form (k_gen_accum_mfma): (weighted, waves, blocks per wave, staged joint rows) -> instantiation
-int launch_gen_accum_mfma(const DevModel& d, const Workspace& ws, int B, bool weighted, float* vextra, const float* tj,
+int launch_gen_accum_mfma(const DevModel& d, const Workspace& ws, int B, bool weighted, double* vextra, const float* tj,
                           const float* jw, hipStream_t st) {
   const size_t lds = gen2_lds(d.J, d.S, d.KW);
   if (lds > 160 * 1024) return fail(SMPLFIT_ERR_UNSUPPORTED, "general path: too many shape unknowns for the accumulate kernel's LDS tile");
   const bool stage = gen2_stage_joints(d.J, d.S, d.KW);
   const int nw = gen2_nw(d.S), nbw = gen2_nbw(d.S);
   const dim3 grid(B, gen2_groups(d.S));
+  // blend passes (64 / 128 vertices) between two additions of the fp32 accumulators to the fp64 record: a scaled
+  // iteration after every pass, the others after 2048 vertices (k_gen_accum_mfma; +2.5 % of its time, 1024: +5 %)
+  const int flush_every = vextra ? 1 : std::max(1, (tune().gen_flush ? tune().gen_flush : 2048) / gen2_sv(d.S));
 #define SF_GEN2(W_, NW_, NBW_, ST_)                                                                                   \
   do {                                                                                                                \
     static std::once_flag once_[16];                                                                                  \
     int dev_ = 0;                                                                                                     \
     (void)hipGetDevice(&dev_);                                                                                        \
     std::call_once(once_[dev_ & 15], [] { set_max_lds_once(reinterpret_cast<const void*>(&k_gen_accum_mfma<W_, NW_, NBW_, ST_>)); }); \
-    hipLaunchKernelGGL((k_gen_accum_mfma<W_, NW_, NBW_, ST_>), grid, dim3(64 * NW_), lds, st, d, ws, B, vextra, tj, jw); \
+    hipLaunchKernelGGL((k_gen_accum_mfma<W_, NW_, NBW_, ST_>), grid, dim3(64 * NW_), lds, st, d, ws, B, vextra, flush_every, tj, jw); \
   } while (0)
 #define SF_GEN2_W(NW_, NBW_, ST_)               \
   do {                                          \
@@ -757,8 +770,8 @@ int launch_gen_accum_mfma(const DevModel& d, const Workspace& ws, int B, bool we
 // joint block of k_joint_stage)
 bool gen_joint_rows(const DevModel& d) { return d.general && tune().gen_mfma; }
 int launch_gen_accum(const DevModel& d, const Workspace& ws, int B, bool weighted, hipStream_t st, const float* jrows_tj,
-                     const float* jrows_jw) {
-  if (tune().gen_mfma) return launch_gen_accum_mfma(d, ws, B, weighted, nullptr, jrows_tj, jrows_jw, st);
+                     const float* jrows_jw, bool extras) {
+  if (tune().gen_mfma) return launch_gen_accum_mfma(d, ws, B, weighted, extras ? ws.gvex : nullptr, jrows_tj, jrows_jw, st);
   const size_t lds = gen_accum_lds(d.J, d.S, d.KW);
   if (lds > 160 * 1024) return fail(SMPLFIT_ERR_UNSUPPORTED, "general path: too many shape unknowns for the accumulate kernel's LDS tile");
   const bool stage = gen_accum_stage_joints(d.J, d.S, d.KW);
@@ -813,9 +826,10 @@ void launch_gen_lbs(const DevModel& d, const Workspace& ws, int B, bool weighted
 }
 // the vertex block / the LBS pass of the wave-per-instance path OR the general one, by model
 // jrows_tj / jrows_jw: the centred target joints (and their weights) when gen_joint_rows() moved the joint block here
+// extras: also the extra sums of a scale unknown (general path: ws.gvex; the other paths run k_scale_extras)
 int launch_accum_any(const DevModel& d, const Workspace& ws, int B, bool weighted, hipStream_t st,
-                     const float* jrows_tj = nullptr, const float* jrows_jw = nullptr) {
-  if (d.general) return launch_gen_accum(d, ws, B, weighted, st, jrows_tj, jrows_jw);
+                     const float* jrows_tj = nullptr, const float* jrows_jw = nullptr, bool extras = false) {
+  if (d.general) return launch_gen_accum(d, ws, B, weighted, st, jrows_tj, jrows_jw, extras);
 #define SF_CALL_ACCUM(S_, KW_) launch_shape_accum<S_, KW_>(d, ws, B, weighted, st)
   SF_DISPATCH_SKW(d, SF_CALL_ACCUM);
 #undef SF_CALL_ACCUM
@@ -995,26 +1009,28 @@ void launch_refine(const DevModel& d, RefineArgs ra, const Workspace& ws, int B,
     hipLaunchKernelGGL(k_refine_epilogue<64>, dim3(B), dim3(64), joint_lds(d, 1), st, d, ra, ws);
   }
 }
+// first / count / cen_b0: a sub-range of the batch (general path: the chunks of a share_beta solve, see share_sum); the
+// other paths always launch the whole batch
 void launch_shape_solve(const DevModel& d, const Workspace& ws, int B, hipStream_t st, float beta_reg, float beta_reg2,
-                        float kid_reg, int pair_form, int use_ref, int mode = 0) {
-  if (stage_half(d, 2, B)) {
+                        float kid_reg, int pair_form, int use_ref, int mode = 0, int first = 0, int count = -1,
+                        int cen_b0 = 0) {
+  if (count < 0) count = B;
+  if (d.general) {
+    static std::once_flag once[16];
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    std::call_once(once[dev_id & 15], [] { set_max_lds_once(reinterpret_cast<const void*>(&k_shape_solve<64, true>)); });
+    hipLaunchKernelGGL((k_shape_solve<64, true>), dim3(count), dim3(d.S > 128 ? 1024 : d.S > 64 ? 256 : 64), solve_lds(d), st, d,
+                       ws, B, beta_reg, beta_reg2, kid_reg, pair_form, use_ref, mode, first, cen_b0);
+  } else if (stage_half(d, 2, B)) {
     hipLaunchKernelGGL(k_shape_solve<32>, dim3(B / 2), dim3(64), 2 * solve_lds(d), st, d, ws, B, beta_reg,
-                       beta_reg2, kid_reg, pair_form, use_ref, mode, 0);
+                       beta_reg2, kid_reg, pair_form, use_ref, mode, 0, 0);
     if (B & 1)
       hipLaunchKernelGGL(k_shape_solve<64>, dim3(1), dim3(64), solve_lds(d), st, d, ws, B, beta_reg, beta_reg2,
-                         kid_reg, pair_form, use_ref, mode, B - 1);
+                         kid_reg, pair_form, use_ref, mode, B - 1, 0);
   } else {
-    if (d.general) {
-      static std::once_flag once[16];
-      int dev_id = 0;
-      (void)hipGetDevice(&dev_id);
-      std::call_once(once[dev_id & 15], [] { set_max_lds_once(reinterpret_cast<const void*>(&k_shape_solve<64, true>)); });
-      hipLaunchKernelGGL((k_shape_solve<64, true>), dim3(B), dim3(d.S > 128 ? 1024 : d.S > 64 ? 256 : 64), solve_lds(d), st, d, ws, B, beta_reg,
-                         beta_reg2, kid_reg, pair_form, use_ref, mode, 0);
-    }
-    else
-      hipLaunchKernelGGL(k_shape_solve<64>, dim3(B), dim3(64), solve_lds(d), st, d, ws, B, beta_reg, beta_reg2,
-                         kid_reg, pair_form, use_ref, mode, 0);
+    hipLaunchKernelGGL(k_shape_solve<64>, dim3(B), dim3(64), solve_lds(d), st, d, ws, B, beta_reg, beta_reg2,
+                       kid_reg, pair_form, use_ref, mode, 0, 0);
   }
 }
 
@@ -1060,47 +1076,75 @@ int launch_convert_source(const ConvertSource& src, const DevModel& d_out, const
 // scaled solve (one more unknown; extra vertex sums first) or the shared solve (assemble, sum over the
 // batch [and the ranks], solve the sum).  The all-shared branch of the reference's lstsq_partial_share
 // drops the ridge reference (pt/lstsq.py:45-47): so does this.
+// the sum of the instances' systems of a share_beta solve into ws.censum: `assemble(first, count, cen_b0)` launches the
+// kernel that writes the systems of the instances [first, first + count) to the rows [first - cen_b0, ...) of ws.cen.
+// The partial sums are those of 64 consecutive instances whatever the chunking (general path: the workspace holds
+// share_chunk(B) rows), so the sum does not depend on it.
+template <class Assemble>
+int share_sum(const DevModel& d, const Workspace& ws, int B, const FitOptions& o, hipStream_t st, Assemble assemble) {
+  const int NC = d.S * d.S + d.S, ey = (NC + 511) / 512;
+  const int chunk = d.general ? share_chunk(B) : B;
+  for (int c0 = 0; c0 < B; c0 += chunk) {
+    const int cnt = std::min(chunk, B - c0);
+    assemble(c0, cnt, d.general ? c0 : 0);
+    hipLaunchKernelGGL(k_share_partial, dim3((cnt + 63) / 64, ey), dim3(512), 0, st, ws, cnt, NC, c0 / 64);
+  }
+  hipLaunchKernelGGL(k_share_reduce, dim3(ey), dim3(512), 0, st, ws, (B + 63) / 64, NC);
+  if (o.share_allreduce && o.share_allreduce(o.share_user, ws.censum, NC, (void*)st) != 0)
+    return fail(SMPLFIT_ERR_HIP, "the share_allreduce callback failed");
+  return 0;
+}
+
 int enqueue_solve(const DevModel& d, const Workspace& ws, int B, const FitOptions& o, bool joints, bool eff_v,
                   bool eff_j, const float* jw, int pair_in, int use_ref, bool scaled, hipStream_t st,
                   bool extras_done = false) {
-  if (d.general && (scaled || o.share_beta))
-    return fail(SMPLFIT_ERR_UNSUPPORTED, "models on the general path (more than 16 betas or more than 8 skinning weights per "
-                                         "vertex): scale_target / scale_fit / share_beta are not implemented");
+  if (d.general && scaled && !tune().gen_mfma)
+    return fail(SMPLFIT_ERR_UNSUPPORTED, "general path with SMPLFIT_GEN_MFMA=0: the scale unknown's extra sums come from the "
+                                         "matrix-core accumulate kernel only");
   if (scaled) {
-    // (extras_done: the batch-major accumulate of this iteration has left the extra sums in ws.vextra)
+    // (extras_done: the batch-major accumulate of this iteration has left the extra sums in ws.vextra; general path:
+    // they are entries of the accumulate kernel's rank-k update — its target column — in ws.gvex, joints included)
 #define SF_CALL_EXTRAS(S_, KW_)                                                                       \
   hipLaunchKernelGGL((k_scale_extras<S_, KW_>), dim3(B), dim3(64),                                    \
                      (size_t)d.J * sf::jd_stride(S_) * 4, st, d, ws, eff_v ? 1 : 0)
-    if (!extras_done) SF_DISPATCH_SKW(d, SF_CALL_EXTRAS);
+    if (!extras_done && !d.general) SF_DISPATCH_SKW(d, SF_CALL_EXTRAS);
 #undef SF_CALL_EXTRAS
     ScaledSolveArgs sa{};
-    sa.tj = joints ? ws.tjc : nullptr;
+    const bool joint_rows = gen_joint_rows(d) && joints;  // the joints' terms are in the records already
+    sa.tj = (joints && !joint_rows) ? ws.tjc : nullptr;
     sa.jw = eff_j ? jw : nullptr;
-    sa.joint_block = joints ? 1 : 0;
+    sa.joint_block = (joints && !joint_rows) ? 1 : 0;
     sa.mode = o.scale_mode;
     sa.pair_form = pair_in;
     sa.use_ref = use_ref;
     sa.beta_reg = o.beta_reg; sa.beta_reg2 = o.beta_reg2; sa.kid_reg = o.kid_reg; sa.scale_reg = o.scale_reg;
-    const size_t lds = (size_t)sf::scaled_solve_scratch_floats(d.S) * 4;
+    sa.B = B;
+    const size_t lds = d.general ? (size_t)(sf::kSolvePanel * (d.S + 1) + sf::kSolvePanel) * 8 : (size_t)sf::scaled_solve_scratch_floats(d.S) * 4;
+    const int threads = d.general ? (d.S > 128 ? 1024 : d.S > 64 ? 256 : 64) : 64;
+    auto launch = [&](int first, int count, int cen_b0) {
+      sa.b0 = first;
+      sa.cen_b0 = cen_b0;
+      if (d.general) {
+        static std::once_flag once[16];
+        int dev_id = 0;
+        (void)hipGetDevice(&dev_id);
+        std::call_once(once[dev_id & 15], [] { set_max_lds_once(reinterpret_cast<const void*>(&k_shape_solve_scaled<true>)); });
+        hipLaunchKernelGGL(k_shape_solve_scaled<true>, dim3(count), dim3(threads), lds, st, d, ws, sa);
+      } else {
+        hipLaunchKernelGGL(k_shape_solve_scaled<false>, dim3(count), dim3(64), lds, st, d, ws, sa);
+      }
+    };
     if (o.share_beta) {  // shared shape, own scale: reduced systems, their sum, solve (pt/lstsq.py:50-90)
-      const int NC = d.S * d.S + d.S;
       sa.share = 1;
-      sa.B = B;
-      hipLaunchKernelGGL(k_shape_solve_scaled, dim3(B), dim3(64), lds, st, d, ws, sa);
-      hipLaunchKernelGGL(k_share_partial, dim3((B + 63) / 64), dim3(512), 0, st, ws, B, NC);
-      hipLaunchKernelGGL(k_share_reduce, dim3(1), dim3(512), 0, st, ws, B, NC);
-      if (o.share_allreduce && o.share_allreduce(o.share_user, ws.cen + (size_t)B * NC, NC, (void*)st) != 0)
-        return fail(SMPLFIT_ERR_HIP, "the share_allreduce callback failed");
+      if (int rc = share_sum(d, ws, B, o, st, launch)) return rc;
       sa.share = 2;
     }
-    hipLaunchKernelGGL(k_shape_solve_scaled, dim3(B), dim3(64), lds, st, d, ws, sa);
+    launch(0, B, 0);
   } else if (o.share_beta) {  // assemble per instance, sum over the batch, solve the sum + own translation
-    const int NC = d.S * d.S + d.S;
-    launch_shape_solve(d, ws, B, st, o.beta_reg, o.beta_reg2, o.kid_reg, pair_in, 0, 1);
-    hipLaunchKernelGGL(k_share_partial, dim3((B + 63) / 64), dim3(512), 0, st, ws, B, NC);
-    hipLaunchKernelGGL(k_share_reduce, dim3(1), dim3(512), 0, st, ws, B, NC);
-    if (o.share_allreduce && o.share_allreduce(o.share_user, ws.cen + (size_t)B * NC, NC, (void*)st) != 0)
-      return fail(SMPLFIT_ERR_HIP, "the share_allreduce callback failed");
+    auto assemble = [&](int first, int count, int cen_b0) {
+      launch_shape_solve(d, ws, B, st, o.beta_reg, o.beta_reg2, o.kid_reg, pair_in, 0, 1, first, count, cen_b0);
+    };
+    if (int rc = share_sum(d, ws, B, o, st, assemble)) return rc;
     launch_shape_solve(d, ws, B, st, o.beta_reg, o.beta_reg2, o.kid_reg, pair_in, 0, 2);
   } else {
     launch_shape_solve(d, ws, B, st, o.beta_reg, o.beta_reg2, o.kid_reg, pair_in, use_ref);
@@ -1230,7 +1274,9 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
       else launch_residual_bm(h, ws, B, st);
     } else {
       launch_gemm(d, ws, B, st);
-      if (int rc = launch_accum_any(d, ws, B, eff_v, st, gjr ? tj_rot : nullptr, gjr && eff_j ? jw : nullptr)) return rc;
+      if (int rc = launch_accum_any(d, ws, B, eff_v, st, gjr ? tj_rot : nullptr, gjr && eff_j ? jw : nullptr,
+                                    o.scale_mode && it + 1 == o.num_iter))
+        return rc;
     }
     // K4 stays its own launch: fused into the prologue of the LBS kernel (template flag SOLVE) its
     // ~40 serial barriers stall all four waves of the workgroup and the kernel ran 230 us longer
@@ -2212,7 +2258,8 @@ int smplfit_shape_solve_ex_f32(const smplfit_handle* h, const smplfit_shape_solv
                        scaled);
   } else {
     launch_gemm(d, ws, batch, st);
-    if (int rc = launch_accum_any(d, ws, batch, eff_v, st, gjr ? ja.tj : nullptr, gjr && eff_j ? joint_weights : nullptr)) return rc;
+    if (int rc = launch_accum_any(d, ws, batch, eff_v, st, gjr ? ja.tj : nullptr, gjr && eff_j ? joint_weights : nullptr, scaled))
+      return rc;
     rc = enqueue_solve(d, ws, batch, o, joints, eff_v, eff_j, joint_weights, (!eff_v && !d.general && use_pair_form()) ? 1 : 0,
                        use_ref, scaled, st);
   }

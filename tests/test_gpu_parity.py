@@ -75,12 +75,16 @@ def test_forward_goldens(name, path, model_root, golden, dev, smplfit_env):
     assert 'vertices' not in j and np.abs(j['joints'] - g['fwd_joints']).max() < 2e-6
 
 
+@pytest.mark.parametrize('mfma', ['1', '0'])
 @pytest.mark.parametrize('kind', list(util.GENERAL_KINDS))
-def test_general_goldens(kind, model_root, golden, dev):
+def test_general_goldens(kind, mfma, model_root, golden, dev, smplfit_env):
     """Models of the GENERAL path (smplfit_info.vertex_path == 2): 32 betas, num_betas=None on a 300-column file (the
     reference's _fit_shape_general, pt/bodyfitter.py:202, 1104-1319), twelve skinning weights per vertex — forward, the
-    fits of golden_general.npz and the conversion BodyConverter runs, against the reference's outputs."""
+    fits of golden_general.npz and the conversion BodyConverter runs, against the reference's outputs.  mfma: the vertex
+    block on the matrix cores (k_gen_accum_mfma, with the target joints as rows of the same update: the default) or on
+    the vector ALUs (SMPLFIT_GEN_MFMA=0: k_gen_accum + the joint block of k_joint_stage)."""
     from smplfitter_amd import _lib
+    smplfit_env('SMPLFIT_GEN_MFMA', mfma)
     from smplfitter_amd.pt import BodyConverter, BodyFitter, BodyModel
 
     gg = golden('general')
@@ -118,10 +122,7 @@ def test_general_goldens(kind, model_root, golden, dev):
     vb = om64.forward(ref['pose_rotvecs'], ref['shape_betas'], ref['trans'])['vertices']
     assert np.linalg.norm(va - vb, axis=-1).max() < 1e-4
     # options the general path does not implement raise (never a silently different result)
-    with pytest.raises(NotImplementedError):
-        fitters[False].fit(t(gg[pre + 'target_vertices'], dev), t(gg[pre + 'target_joints'], dev), share_beta=True)
-    with pytest.raises(NotImplementedError):
-        fitters[False].fit(t(gg[pre + 'target_vertices'], dev), t(gg[pre + 'target_joints'], dev), scale_target=True)
+    # (share_beta and the scale unknowns on this path: test_general_option_goldens)
     # run to run: bit-identical
     tv, kw = util.general_fit_args(gg, kind, 'it3_reg1_j_nw_fa')
     kw = {k: (t(v, dev) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
@@ -900,6 +901,37 @@ def test_share_scale_goldens(name, model_root, golden, dev):
         util.check_share_scale(om, name, case, o, gk, kid_fit)
         n += 1
     assert n >= 1
+
+
+@pytest.mark.parametrize('kind', list(util.GENERAL_OPT_KINDS))
+def test_general_option_goldens(kind, model_root, golden, dev):
+    """scale_target / scale_fit / share_beta (and both) on models of the GENERAL path against the reference
+    (golden_general_opts.npz): the scale unknown's extra sums are entries of the same rank-k update as the vertex block
+    (the target column of k_gen_accum_mfma), the shared solve sums the instances' systems chunk by chunk."""
+    from smplfitter_amd import _lib
+    from smplfitter_amd.pt import BodyFitter, BodyModel
+
+    gg, go = golden('general'), golden('general_opts')
+    g, ge = util.general_view(gg, kind), util.general_view(go, kind)
+    cases = util.GENERAL_OPT_KINDS[kind]
+    m = BodyModel('smpl', 'neutral', model_root=f'{model_root}/{kind}', num_betas=util.GENERAL_KINDS[kind], device=dev)
+    assert m._native(dev).info.vertex_path == _lib.SMPLFIT_PATH_GENERAL
+    om = util.general_oracle(model_root, kind, np.float64)
+    om32 = util.general_oracle(model_root, kind)
+    fitters = {False: BodyFitter(m), True: BodyFitter(m, enable_kid=True)}
+    tt = lambda kw: {k: (t(v, dev) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}  # noqa: E731
+    for case in cases['scale']:
+        kid_fit, tv, kw = util.scale_inputs(g, case)
+        o = to_np(fitters[kid_fit].fit(t(tv, dev), requested_keys=['pose_rotvecs', 'shape_betas', 'trans', 'scale_corr'], **tt(kw)))
+        util.check_scale(om, 'smpl', case, o, ge, kid_fit)
+    for case in cases['share']:
+        kid_fit, tv, kw = util.share_inputs(g, om32, case)
+        o = to_np(fitters[kid_fit].fit(t(tv, dev), share_beta=True, requested_keys=['pose_rotvecs'], **tt(kw)))
+        util.check_share(om, 'smpl', case, o, ge, kid_fit)
+    for case in cases['sharescale']:
+        kid_fit, tv, kw = util.share_scale_inputs(g, om32, case)
+        o = to_np(fitters[kid_fit].fit(t(tv, dev), share_beta=True, requested_keys=['pose_rotvecs'], **tt(kw)))
+        util.check_share_scale(om, 'smpl', case, o, ge, kid_fit)
 
 
 def _share_rank(rank, world, backend, port, root, tmp):

@@ -285,6 +285,30 @@ def test_share_scale_goldens(name, model_root, golden):
     assert n >= 1
 
 
+@pytest.mark.parametrize('kind', list(util.GENERAL_OPT_KINDS))
+def test_general_option_goldens(kind, model_root, golden):
+    """scale_target / scale_fit / share_beta (and both) on models of the general path against the reference
+    (golden_general_opts.npz; the reference's _fit_shape_general carries them as one more column / a partially shared
+    solve, pt/bodyfitter.py:1170-1175, pt/lstsq.py:50-90): the fp64 oracle at the gates of the other fixtures."""
+    gg, go = golden('general'), golden('general_opts')
+    g, ge = util.general_view(gg, kind), util.general_view(go, kind)
+    cases = util.GENERAL_OPT_KINDS[kind]
+    om = util.general_oracle(model_root, kind, np.float64)
+    om32 = util.general_oracle(model_root, kind)
+    fitters = {False: O.OracleFitter(om), True: O.OracleFitter(om, enable_kid=True)}
+    for case in cases['scale']:
+        kid_fit, tv, kw = util.scale_inputs(g, case)
+        util.check_scale(om, 'smpl', case, fitters[kid_fit].fit(tv, **kw), ge, kid_fit)
+    for case in cases['share']:
+        kid_fit, tv, kw = util.share_inputs(g, om32, case)
+        assert np.array_equal(tv[:, ::300], ge[f'share.{case}.target_vertices_sub'])
+        util.check_share(om, 'smpl', case, fitters[kid_fit].fit(tv, share_beta=True, **kw), ge, kid_fit)
+    for case in cases['sharescale']:
+        kid_fit, tv, kw = util.share_scale_inputs(g, om32, case)
+        assert np.array_equal(tv[:, ::300], ge[f'sharescale.{case}.target_vertices_sub'])
+        util.check_share_scale(om, 'smpl', case, fitters[kid_fit].fit(tv, share_beta=True, **kw), ge, kid_fit)
+
+
 @pytest.mark.parametrize('nb', [6, 13])
 def test_num_betas_goldens(nb, model_root, golden):
     """The oracle against the reference's fixture for num_betas = 6 / 13 (golden_nb_smpl.npz)."""

@@ -60,6 +60,25 @@ def load_general_md(root, kind):
     return modelio.load_model('smpl', 'neutral', model_root=f'{root}/{kind}', num_betas=GENERAL_KINDS[kind])
 
 
+# options of fit on the general path (tests/golden/make_golden_general_opts.py): the cases of SCALE_CASES / SHARE_CASES /
+# SHARE_SCALE_CASES run per model (case d of SCALE_CASES — kid + scale, nearly collinear on the synthetic model — is left
+# to the fixtures of the other paths)
+GENERAL_OPT_KINDS = {
+    'smpl_b32': dict(scale=('a', 'b', 'c', 'e'), share=('a', 'b', 'c'), sharescale=('a', 'c')),
+    'smpl_w12': dict(scale=('a', 'c'), share=('b',), sharescale=()),
+}
+
+
+def general_view(gg, kind):
+    """The arrays of one model of golden_general.npz under the names the fixtures of the other paths use."""
+    pre = kind + '.'
+    return {k[len(pre):]: v for k, v in gg.items() if k.startswith(pre) and '.fit.' not in k}
+
+
+def general_oracle(root, kind, dtype=np.float32):
+    return O.OracleModel(load_general_md(root, kind), dtype, 'smpl')
+
+
 def general_fit_args(gg, kind, case):
     """(target_vertices, keyword arguments) of a fixture case, as numpy arrays."""
     c = GENERAL_CASES[case]
