@@ -25,7 +25,7 @@ def pytest_configure(config):
 def model_root():
     from smplfitter_amd import synth
 
-    return synth.ensure_model_root(kinds=('smpl', 'smplx', 'smplx_fat', 'smpl_b16', 'smpl_w6_b16', 'smpl_w6', 'smplx_w6', 'smpl_rnd', 'smpl_b32', 'smpl_b300', 'smpl_w12'),
+    return synth.ensure_model_root(kinds=('smpl', 'smplx', 'smplx_fat', 'smpl_b16', 'smpl_w6_b16', 'smpl_w6', 'smplx_w6', 'smpl_rnd', 'smpl_b32', 'smpl_b300', 'smpl_w12', 'smpl_b100', 'smpl_b400'),
                                    seed=0)
 
 

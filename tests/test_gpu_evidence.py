@@ -406,7 +406,7 @@ def test_workspace_guards(name, model_root, golden, dev):
 @pytest.mark.parametrize('kind,nb', [('smpl_w6', 10), ('smpl_b16', 16), ('smpl_b32', 32), ('smpl_w12', 10)])
 def test_workspace_guards_round5_paths(kind, nb, model_root, dev):
     """The same guard / NaN-poison check on the kernels of round 5: pieces of eight joints (smpl_w6) and 16 betas (smpl_b16)
-    on the batch-major kernels, and the general path (smpl_b32, smpl_w12: k_gen_accum / k_gen_lbs, stage scratch in the
+    on the batch-major kernels, and the general path (smpl_b32, smpl_w12: k_gen_accum_mfma / k_gen_lbs, stage scratch in the
     workspace) — default fit with a partial last block, the kid unknown, joints omitted, weights, a small batch, known
     shape, known pose."""
     from smplfitter_amd.pt import BodyFitter, BodyModel
@@ -429,6 +429,13 @@ def test_workspace_guards_round5_paths(kind, nb, model_root, dev):
         (f, False, dict(_call='known_shape', num_iter=2)),
         (f, False, dict(_call='known_pose')),
     ]
+    if m.kernel_path() == 'general':  # the options the general path gained last: the scaled solve's fp64 extras, the
+        cases += [                    # chunked share sums (300 instances: two chunks), both together
+            (f, False, dict(num_iter=2, beta_regularizer=1.0, scale_target=True)),
+            (f, False, dict(num_iter=2, beta_regularizer=1.0, scale_fit=True, vertex_weights=vw, joint_weights=jw)),
+            (f, False, dict(num_iter=2, beta_regularizer=1.0, share_beta=True)),
+            (fk, False, dict(num_iter=2, beta_regularizer=1.0, share_beta=True, scale_fit=True)),
+        ]
     zeros_pose, zeros_betas = torch.zeros(B, 3 * m.num_joints, device=dev), torch.zeros(B, nb, device=dev)
     for fitter, no_joints, kw in cases:
         kw = dict(kw)

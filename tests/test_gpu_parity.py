@@ -131,13 +131,15 @@ def test_general_goldens(kind, mfma, model_root, golden, dev, smplfit_env):
     assert all(np.array_equal(a[k], b[k]) for k in a)
 
 
-@pytest.mark.parametrize('kind,B', [('smpl_b32', 1024), ('smpl_w12', 1024), ('smpl_b300', 96)])
+@pytest.mark.parametrize('kind,B', [('smpl_b32', 1024), ('smpl_w12', 1024), ('smpl_b300', 96), ('smpl_b100', 64), ('smpl_b400', 24)])
 def test_general_full_size(kind, B, model_root, dev):
     """The general path at larger batches on fresh seeded inputs (+ 5 mm noise): samples against the fp64 oracle, run to
-    run bit-identical, a slice fitted alone gives the same bits, the other entry points (known shape / known pose)."""
+    run bit-identical, a slice fitted alone gives the same bits, the other entry points (known shape / known pose).
+    smpl_b100 / smpl_b400: the workgroup shapes of the accumulate kernel the fixtures do not reach (sixteen waves of one
+    block; two workgroups per instance, joint rows not staged)."""
     from smplfitter_amd.pt import BodyFitter, BodyModel
 
-    nb = util.GENERAL_KINDS[kind]
+    nb = util.general_num_betas(kind)
     m = BodyModel('smpl', 'neutral', model_root=f'{model_root}/{kind}', num_betas=nb, device=dev)
     f = BodyFitter(m)
     S, J = m.num_betas, m.num_joints

@@ -56,8 +56,17 @@ GENERAL_CASES = {
 }
 
 
+# further models of the general path without a fixture of their own (checked against the fp64 oracle): 100 betas — the
+# accumulate kernel's sixteen-wave workgroup shape — and 400 — its 91 blocks split over two workgroups per instance
+GENERAL_SHAPE_KINDS = {'smpl_b100': 100, 'smpl_b400': 400}
+
+
+def general_num_betas(kind):
+    return GENERAL_KINDS[kind] if kind in GENERAL_KINDS else GENERAL_SHAPE_KINDS[kind]
+
+
 def load_general_md(root, kind):
-    return modelio.load_model('smpl', 'neutral', model_root=f'{root}/{kind}', num_betas=GENERAL_KINDS[kind])
+    return modelio.load_model('smpl', 'neutral', model_root=f'{root}/{kind}', num_betas=general_num_betas(kind))
 
 
 # options of fit on the general path (tests/golden/make_golden_general_opts.py): the cases of SCALE_CASES / SHARE_CASES /
