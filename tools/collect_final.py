@@ -14,7 +14,7 @@ for c in ('c3', 'c4', 'c5'):
     shutil.copy(f'{F}/bench_{c}.json', f'{P}/{tag}_bench_{c}.json')
 shutil.copy(f'{F}/bench_callers.txt', f'{P}/{tag}_bench_callers.txt')
 shutil.copy(f'{F}/latency.json', f'{P}/{tag}_latency.json')
-for n in ('bench_skin.json', 'bench_general.json', 'wave_stamps_4096.txt'):
+for n in ('bench_skin.json', 'bench_general.json', 'kstats_general.txt', 'pmc_general.json', 'wave_stamps_4096.txt'):
     if os.path.exists(f'{F}/{n}'):
         shutil.copy(f'{F}/{n}', f'{P}/{tag}_{n}')
 build = json.load(open(f'{P}/{tag}_bench_c3.json'))['build']

@@ -19,4 +19,27 @@ timeout 300 python tools/bench_callers.py > $F/bench_callers.txt 2>$F/bench_call
 timeout 200 python tools/latency.py > $F/latency.json 2>$F/latency.err < /dev/null; tail -2 $F/latency.json | cut -c1-300
 timeout 200 python tools/bench_skin.py > $F/bench_skin.json 2>/dev/null < /dev/null; cat $F/bench_skin.json
 timeout 300 python tools/bench_general.py > $F/bench_general.json 2>/dev/null < /dev/null; cat $F/bench_general.json
+# the general path: per-kernel statistics (300 betas at B = 256 and 2048, 32 betas at 4096) and the A/B against the
+# vector-ALU form of the vertex block
+{ for a in "smpl_b300" "smpl_b300 2048" "smpl_b32" "smpl_w12"; do echo "== $a"; timeout 300 bash tools/kstats_general.sh $a; done
+  for a in "smpl_b300" "smpl_b32"; do echo "== $a SMPLFIT_GEN_MFMA=0"; SMPLFIT_GEN_MFMA=0 timeout 300 bash tools/kstats_general.sh $a; done; } > $F/kstats_general.txt 2>&1 < /dev/null
+grep -A2 "^==" $F/kstats_general.txt | head -30
+# matrix-pipe counters of the general accumulate kernel (300 betas, B = 256)
+(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pmcgen && timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --output-format csv -d /tmp/pmcgen -o p -- python $R/tools/bench_general.py smpl_b300 > /dev/null 2>&1 < /dev/null)
+python - > $F/pmc_general.json <<'PY'
+import csv, glob, json, collections, re
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob('/tmp/pmcgen/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        m = re.search(r'(k_[a-z_0-9]+)', r['Kernel_Name'])
+        if m and m.group(1) in ('k_gen_accum_mfma', 'k_shape_solve', 'k_gen_lbs'):
+            acc[m.group(1)][r['Counter_Name']].append(float(r['Counter_Value']))
+res = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+for k, e in res.items():
+    if e.get('SQ_BUSY_CU_CYCLES'):
+        e['mfma_busy_frac_per_simd'] = e.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / e['SQ_BUSY_CU_CYCLES'] / 4
+res['_note'] = 'rocprofv3 --pmc, tools/bench_general.py smpl_b300 (B = 256): per-launch averages'
+print(json.dumps(res, indent=1))
+PY
+head -c 900 $F/pmc_general.json
 SMPLFIT_LIB=build_ab/libwstamp.so timeout 200 python tools/wave_stamps.py 4096 > $F/wave_stamps_4096.txt 2>&1 < /dev/null; head -12 $F/wave_stamps_4096.txt
