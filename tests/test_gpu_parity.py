@@ -936,6 +936,39 @@ def test_general_option_goldens(kind, model_root, golden, dev):
         util.check_share_scale(om, 'smpl', case, o, ge, kid_fit)
 
 
+def test_general_share_two_chunks(model_root, dev):
+    """share_beta on the general path with more instances than one chunk of the workspace's system rows (300 > 256: the
+    instances' systems are written and summed chunk by chunk): one shape for the batch, against the fp64 oracle, run to
+    run identical."""
+    from smplfitter_amd.pt import BodyFitter, BodyModel
+
+    kind = 'smpl_b32'
+    m = BodyModel('smpl', 'neutral', model_root=f'{model_root}/{kind}', num_betas=32, device=dev)
+    om = util.general_oracle(model_root, kind, np.float64)
+    B = 300
+    rs = np.random.RandomState(5)
+    pose, betas, trans = rs.randn(B, 72) * 0.1, np.repeat(rs.randn(1, 32) * 0.5, B, 0), rs.randn(B, 3)
+    fw = om.forward(pose, betas, trans)
+    tv = (fw['vertices'] + rs.randn(*fw['vertices'].shape) * 0.003).astype(np.float32)
+    tj = fw['joints'].astype(np.float32)
+    kw = dict(num_iter=2, beta_regularizer=1.0, share_beta=True)
+    f = BodyFitter(m)
+    o = to_np(f.fit(t(tv, dev), t(tj, dev), requested_keys=['pose_rotvecs'], **kw))
+    o2 = to_np(f.fit(t(tv, dev), t(tj, dev), requested_keys=['pose_rotvecs'], **kw))
+    for k in ('pose_rotvecs', 'shape_betas', 'trans'):
+        assert np.array_equal(o[k], o2[k]), k
+    assert np.abs(o['shape_betas'] - o['shape_betas'][:1]).max() == 0
+    ref = util.O.OracleFitter(om).fit(tv, tj, **kw)
+    assert np.abs(o['shape_betas'] - ref['shape_betas']).max() < 1e-3
+    assert np.abs(o['trans'] - ref['trans']).max() < 1e-4
+    idx = np.array([0, 1, 255, 256, 257, B - 1])
+    va = om.forward(o['pose_rotvecs'][idx], o['shape_betas'][idx], o['trans'][idx])['vertices']
+    vb = om.forward(ref['pose_rotvecs'][idx], ref['shape_betas'][idx], ref['trans'][idx])['vertices']
+    err = np.linalg.norm(va - vb, axis=-1).max()
+    print(f'[general share, 2 chunks] betas {np.abs(o["shape_betas"] - ref["shape_betas"]).max():.2e} vtx {err:.2e}')
+    assert err < 5e-4
+
+
 def _share_rank(rank, world, backend, port, root, tmp):
     """One rank of a sharded share_beta fit; every rank drives cuda:0 (the box has one GPU)."""
     import torch.distributed as dist
