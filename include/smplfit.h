@@ -94,7 +94,8 @@ typedef struct smplfit_info {
                                   10 or 16 betas with or without the kid unknown, >= 1024 vertices),
                                   SMPLFIT_PATH_WAVE (one wave per instance: small subsets, non-normalised weights —
                                   about 0.4x the rate) or SMPLFIT_PATH_GENERAL (any number of betas up to 1023 / of
-                                  skinning weights up to 64: run-time loops)                       */
+                                  skinning weights up to 64: run-time loops, the normal equations as one rank-k
+                                  update on the matrix cores, every option of the fit)              */
   int32_t share_fallback;      /* bit k: cell table k (see smplfit_get_share_table) is a copy of a wider or coarser
                                   one because its own domain was too small for its cells; 0xffff: the model has
                                   no cell tables at all (SMPLFIT_PATH_WAVE)                                        */
