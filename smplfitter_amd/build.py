@@ -15,8 +15,18 @@ HERE = osp.dirname(osp.abspath(__file__))
 CSRC = osp.join(HERE, 'csrc')
 OUT = osp.join(HERE, 'libsmplfit_hip.so')
 SOURCES = ['smplfit_hip.hip', 'sf_tables.cpp']
-HEADERS = ['sf_math.h', 'sf_stages.h', 'sf_tables.h', 'kernels_wave.inc', 'kernels_bm.inc',
-           '../../include/smplfit.h']
+
+
+def _headers():
+    """Every file under csrc/ that is not a translation unit, plus the public header: the list is read
+    from the directory, so a new ``*.inc`` / ``*.h`` is part of ``needs_build()`` and of the build id the
+    moment it exists (``tests/test_cabi.py::test_build_id_covers_csrc``)."""
+    own = sorted(f for f in os.listdir(CSRC)
+                 if f not in SOURCES and f.endswith(('.h', '.inc', '.hip', '.cpp', '.hpp')))
+    return own + ['../../include/smplfit.h']
+
+
+HEADERS = _headers()
 
 
 def _hipcc():
@@ -30,7 +40,7 @@ def needs_build():
     if not osp.exists(OUT):
         return True
     t = osp.getmtime(OUT)
-    return any(osp.getmtime(osp.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return any(osp.getmtime(osp.join(CSRC, f)) > t for f in SOURCES + _headers())
 
 
 def source_id():
@@ -39,7 +49,7 @@ def source_id():
     import hashlib
 
     h = hashlib.sha256()
-    for f in sorted(SOURCES + HEADERS):
+    for f in sorted(SOURCES + _headers()):
         with open(osp.join(CSRC, f), 'rb') as fh:
             h.update(f.encode() + b'\0' + fh.read())
     return h.hexdigest()[:12]

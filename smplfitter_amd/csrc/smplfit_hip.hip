@@ -95,6 +95,11 @@ struct ShareView {
   int rec;   // ints per piece record: 12, or 24 for pieces of up to eight joints (sf::HostTables::piece_rec)
   int mult;  // cells per wave: share s walks the cells [s * mult, (s + 1) * mult)
   int fine;  // the fine table of its kind (small batches): the combine kernels split the rows over waves
+  int max_aux;  // longest CSR run of aux_rows (a joint's moment rows / a part's rows)
+  // residual tables: the CSR as rows of aux_pitch (max_aux rounded up to 16) entries per joint, -1 behind a joint's last
+  // row (k_solve_bm)
+  const int32_t* aux_pad;
+  int aux_pitch;
 };
 
 }  // namespace
@@ -248,6 +253,21 @@ struct Workspace {
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Kernels that may ask for more than 64 KB of dynamic LDS: the attribute is set once per (device, kernel) — a list
+// under a mutex, so that every device id has its own entry (round 5 kept 16 flags indexed by id & 15: the ids from 16
+// up shared a flag with a lower id and never got the attribute)
+void ensure_max_lds(const void* fn) {
+  static std::mutex mu;
+  static std::vector<std::pair<int, const void*>> done;
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  std::lock_guard<std::mutex> lock(mu);
+  for (const auto& e : done)
+    if (e.first == dev_id && e.second == fn) return;
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  done.emplace_back(dev_id, fn);
+}
 
 // Work units of k_pair_gram_bm (kernels_bm.inc): every joint twice + chunks of kPgPairs joint pairs; a workgroup of
 // kPgWaves waves takes kPgWaves units and writes ONE upper triangle to ws.gramP.  Shared by the workspace carve, the
@@ -406,6 +426,7 @@ struct Tuning {
   int bm_slots = 4096;     // SMPLFIT_BM_SLOTS: resident waves a batch-major vertex pass is dealt for (share-count choice)
   int gen_flush = 0;       // SMPLFIT_GEN_FLUSH: vertices between two fp64 additions of the general accumulate kernel's fp32 sums (0: 2048; a scaled iteration: every blend pass)
   bool gen_mfma = true;    // SMPLFIT_GEN_MFMA=0: the general path's vertex block on the vector ALUs (k_gen_accum) instead of the matrix cores (A/B)
+  bool solve_bm = true;    // SMPLFIT_SOLVE_BM=0: normal-equation combine + wave-per-instance solve as two launches instead of k_solve_bm (A/B)
   int bm_lds_kb = 0;       // SMPLFIT_BM_LDS_KB: LDS request of the two batch-major vertex passes padded to this (54: three
                            // workgroups per CU instead of four, which leaves registers / LDS for another chunk's small kernels)
 };
@@ -435,6 +456,7 @@ Tuning read_tuning() {
   if (const char* e = env("SMPLFIT_BM_SLOTS")) t.bm_slots = std::min(std::max(atoi(e), 256), 16384);
   if (const char* e = env("SMPLFIT_GEN_MFMA")) t.gen_mfma = e[0] != '0';
   if (const char* e = env("SMPLFIT_GEN_FLUSH")) t.gen_flush = std::max(atoi(e), 0);
+  if (const char* e = env("SMPLFIT_SOLVE_BM")) t.solve_bm = e[0] != '0';
   if (const char* e = env("SMPLFIT_BM_LDS_KB")) t.bm_lds_kb = std::min(std::max(atoi(e), 0), 64);
   return t;
 }
@@ -618,24 +640,27 @@ void launch_lbs_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStrea
 
 // the forward-only variant of the batch-major LBS pass (posed vertices left in ws.vpT): input side of a fused
 // conversion, BodyModel.forward, the mesh of a shape solve
-void launch_lbs_fwd_bm(const DevModel& d, const ShareView& sv, const Workspace& ws, int B, int Mp, hipStream_t st) {
+int launch_lbs_fwd_bm(const DevModel& d, const ShareView& sv, const Workspace& ws, int B, int Mp, hipStream_t st) {
   const dim3 grid = share_grid(sv, Mp);
 #define SF_FWD(S_, KW_) hipLaunchKernelGGL((k_lbs_partsum_bm<S_, KW_, true, true>), grid, dim3(64 * kBW), 0, st, d, sv, ws, B, Mp)
   if (d.KW == 8) {
     switch (d.S) {
       case 11: SF_FWD(11, 8); break;
       case 16: SF_FWD(16, 8); break;
-      default: SF_FWD(10, 8);
+      case 10: SF_FWD(10, 8); break;
+      default: return fail(SMPLFIT_ERR_UNSUPPORTED, "forward LBS pass: no batch-major kernel for this (betas, skinning width)");
     }
   } else {
     switch (d.S) {
       case 11: SF_FWD(11, 4); break;
       case 16: SF_FWD(16, 4); break;
       case 17: SF_FWD(17, 4); break;
-      default: SF_FWD(10, 4);
+      case 10: SF_FWD(10, 4); break;
+      default: return fail(SMPLFIT_ERR_UNSUPPORTED, "forward LBS pass: no batch-major kernel for this (betas, skinning width)");
     }
   }
 #undef SF_FWD
+  return 0;
 }
 
 template <int S, int KW>
@@ -691,15 +716,8 @@ void launch_center_sort(const DevModel& d, const float* tv, const float* tj, con
   if (lds_row <= 160 * 1024) {
     // dynamic LDS above 64 KB has to be opted into once per kernel (and per device: the attribute is
     // set again whenever the current device changes; idempotent, so racing threads are harmless)
-    static std::once_flag once[16];
-    int dev_id = 0;
-    (void)hipGetDevice(&dev_id);
-    std::call_once(once[dev_id & 15], [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_center_sort_partsum_lds<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_center_sort_partsum_lds<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
+    ensure_max_lds(reinterpret_cast<const void*>(&k_center_sort_partsum_lds<true>));
+    ensure_max_lds(reinterpret_cast<const void*>(&k_center_sort_partsum_lds<false>));
     if (vw)
       hipLaunchKernelGGL((k_center_sort_partsum_lds<true>), dim3(B), dim3(1024), lds_row, st, d, tv, tj, vw, ws, VL);
     else
@@ -728,7 +746,6 @@ void launch_center_sort(const DevModel& d, const float* tv, const float* tj, con
 
 // GENERAL path (kernels_gen.inc): the vertex block of the normal equations and the LBS / part-sum pass with run-time
 // loops over the unknowns and the skinning weights
-void set_max_lds_once(const void* fn) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
 // the matrix-core form (k_gen_accum_mfma): (weighted, waves, blocks per wave, staged joint rows) -> instantiation
 int launch_gen_accum_mfma(const DevModel& d, const Workspace& ws, int B, bool weighted, double* vextra, const float* tj,
                           const float* jw, hipStream_t st) {
@@ -742,10 +759,7 @@ int launch_gen_accum_mfma(const DevModel& d, const Workspace& ws, int B, bool we
   const int flush_every = vextra ? 1 : std::max(1, (tune().gen_flush ? tune().gen_flush : 2048) / gen2_sv(d.S));
 #define SF_GEN2(W_, NW_, NBW_, ST_)                                                                                   \
   do {                                                                                                                \
-    static std::once_flag once_[16];                                                                                  \
-    int dev_ = 0;                                                                                                     \
-    (void)hipGetDevice(&dev_);                                                                                        \
-    std::call_once(once_[dev_ & 15], [] { set_max_lds_once(reinterpret_cast<const void*>(&k_gen_accum_mfma<W_, NW_, NBW_, ST_>)); }); \
+    ensure_max_lds(reinterpret_cast<const void*>(&k_gen_accum_mfma<W_, NW_, NBW_, ST_>)); \
     hipLaunchKernelGGL((k_gen_accum_mfma<W_, NW_, NBW_, ST_>), grid, dim3(64 * NW_), lds, st, d, ws, B, vextra, flush_every, tj, jw); \
   } while (0)
 #define SF_GEN2_W(NW_, NBW_, ST_)               \
@@ -779,10 +793,7 @@ int launch_gen_accum(const DevModel& d, const Workspace& ws, int B, bool weighte
   // (weighted, vertices per tile, threads, staged joint rows) -> instantiation
 #define SF_GEN(W_, TV_, NT_, ST_)                                                                              \
   do {                                                                                                         \
-    static std::once_flag once_[16];                                                                           \
-    int dev_ = 0;                                                                                              \
-    (void)hipGetDevice(&dev_);                                                                                 \
-    std::call_once(once_[dev_ & 15], [] { set_max_lds_once(reinterpret_cast<const void*>(&k_gen_accum<W_, TV_, NT_, ST_>)); }); \
+    ensure_max_lds(reinterpret_cast<const void*>(&k_gen_accum<W_, TV_, NT_, ST_>)); \
     hipLaunchKernelGGL((k_gen_accum<W_, TV_, NT_, ST_>), dim3(B), dim3(NT_), lds, st, d, ws, B);               \
   } while (0)
 #define SF_GEN_W(TV_, NT_, ST_)              \
@@ -811,10 +822,7 @@ void launch_gen_lbs(const DevModel& d, const Workspace& ws, int B, bool weighted
 #define SF_GLBS(M_, W_)                                                                                                   \
   do {                                                                                                                    \
     if (ni == 4) {                                                                                                        \
-      static std::once_flag once_[16];                                                                                    \
-      int dev_ = 0;                                                                                                       \
-      (void)hipGetDevice(&dev_);                                                                                          \
-      std::call_once(once_[dev_ & 15], [] { set_max_lds_once(reinterpret_cast<const void*>(&k_gen_lbs<M_, W_, 4>)); });   \
+      ensure_max_lds(reinterpret_cast<const void*>(&k_gen_lbs<M_, W_, 4>));   \
       hipLaunchKernelGGL((k_gen_lbs<M_, W_, 4>), dim3((B + 3) / 4), dim3(256), lds, st, d, ws, B, nb, beta, trans, kid, out); \
     } else {                                                                                                              \
       hipLaunchKernelGGL((k_gen_lbs<M_, W_, 1>), dim3(B), dim3(256), lds, st, d, ws, B, nb, beta, trans, kid, out);       \
@@ -881,15 +889,8 @@ int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, b
     nchunk = std::min(nchunk, ntiles);
     const int per = (ntiles + nchunk - 1) / nchunk;  // trailing chunks may be empty (they return at once)
     const size_t lds = (size_t)kGemmRing * kGemmTileBytes;
-    static std::once_flag once[16];
-    int dev_id = 0;
-    (void)hipGetDevice(&dev_id);
-    std::call_once(once[dev_id & 15], [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_posedirs_gemm_bf16x3<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_posedirs_gemm_bf16x3<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
+    ensure_max_lds(reinterpret_cast<const void*>(&k_posedirs_gemm_bf16x3<true>));
+    ensure_max_lds(reinterpret_cast<const void*>(&k_posedirs_gemm_bf16x3<false>));
     if (transposed)
       hipLaunchKernelGGL((k_posedirs_gemm_bf16x3<true>), dim3(nchunk, ny), dim3(64 * kGemmWaves), lds, st, ws.rp,
                          d.pdB, ws.vpT, N, per, Mp);
@@ -903,13 +904,7 @@ int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, b
     const int mt = (Mp + 255) / 256, nt256 = N / 256;
     uint16_t* aimg = reinterpret_cast<uint16_t*>(ws.vposed);
     hipLaunchKernelGGL(k_split_features, dim3(mt, d.kc32), dim3(256), 0, st, ws.rp, aimg, Mp, d.Kp, d.kc32);
-    static std::once_flag once[16];
-    int dev_id = 0;
-    (void)hipGetDevice(&dev_id);
-    std::call_once(once[dev_id & 15], [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_posedirs_gemm_bf16x3_tiled),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
+    ensure_max_lds(reinterpret_cast<const void*>(&k_posedirs_gemm_bf16x3_tiled));
     hipLaunchKernelGGL(k_posedirs_gemm_bf16x3_tiled, dim3(8 * ((mt + 7) / 8) * nt256), dim3(512), (size_t)2 * kTg2Stage, st,
                        aimg, d.pdB2, ws.vpT, N, Mp, mt, d.kc32, sf::rp_pos(d.P, d.Kp) / 16);
     return 0;
@@ -929,15 +924,8 @@ int launch_gemm(const DevModel& d, const Workspace& ws, int B, hipStream_t st, b
       const int pad_kb = tune().gemm_lds_kb;
       if (pad_kb > 0) {
         lds = std::max(lds, (size_t)pad_kb * 1024);
-        static std::once_flag once[16];
-        int dev_id = 0;
-        (void)hipGetDevice(&dev_id);
-        std::call_once(once[dev_id & 15], [] {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_posedirs_gemm_as<NK2, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_posedirs_gemm_as<NK2, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        });
+        ensure_max_lds(reinterpret_cast<const void*>(&k_posedirs_gemm_as<NK2, true>));
+        ensure_max_lds(reinterpret_cast<const void*>(&k_posedirs_gemm_as<NK2, false>));
       }
     }
     if (transposed)
@@ -986,7 +974,7 @@ void launch_joint_stage(const DevModel& d, JointStageArgs ja, const Workspace& w
   ja.B = B;
   ja.b0 = 0;
   if (stage_half(d, 1, B)) {
-    hipLaunchKernelGGL(k_joint_stage<32>, dim3(B / 2), dim3(64), 2 * joint_lds(d), st, d, ja, ws);
+    if (B / 2 > 0) hipLaunchKernelGGL(k_joint_stage<32>, dim3(B / 2), dim3(64), 2 * joint_lds(d), st, d, ja, ws);
     if (B & 1) {  // the odd last instance: a launch of its own (no wave works on one instance twice)
       ja.b0 = B - 1;
       hipLaunchKernelGGL(k_joint_stage<64>, dim3(1), dim3(64), joint_lds(d), st, d, ja, ws);
@@ -1000,7 +988,7 @@ void launch_refine(const DevModel& d, RefineArgs ra, const Workspace& ws, int B,
   ra.B = B;
   ra.b0 = 0;
   if (stage_half(d, 4, B)) {
-    hipLaunchKernelGGL(k_refine_epilogue<32>, dim3(B / 2), dim3(64), 2 * joint_lds(d, 1), st, d, ra, ws);
+    if (B / 2 > 0) hipLaunchKernelGGL(k_refine_epilogue<32>, dim3(B / 2), dim3(64), 2 * joint_lds(d, 1), st, d, ra, ws);
     if (B & 1) {
       ra.b0 = B - 1;
       hipLaunchKernelGGL(k_refine_epilogue<64>, dim3(1), dim3(64), joint_lds(d, 1), st, d, ra, ws);
@@ -1016,15 +1004,13 @@ void launch_shape_solve(const DevModel& d, const Workspace& ws, int B, hipStream
                         int cen_b0 = 0) {
   if (count < 0) count = B;
   if (d.general) {
-    static std::once_flag once[16];
-    int dev_id = 0;
-    (void)hipGetDevice(&dev_id);
-    std::call_once(once[dev_id & 15], [] { set_max_lds_once(reinterpret_cast<const void*>(&k_shape_solve<64, true>)); });
+    ensure_max_lds(reinterpret_cast<const void*>(&k_shape_solve<64, true>));
     hipLaunchKernelGGL((k_shape_solve<64, true>), dim3(count), dim3(d.S > 128 ? 1024 : d.S > 64 ? 256 : 64), solve_lds(d), st, d,
                        ws, B, beta_reg, beta_reg2, kid_reg, pair_form, use_ref, mode, first, cen_b0);
   } else if (stage_half(d, 2, B)) {
-    hipLaunchKernelGGL(k_shape_solve<32>, dim3(B / 2), dim3(64), 2 * solve_lds(d), st, d, ws, B, beta_reg,
-                       beta_reg2, kid_reg, pair_form, use_ref, mode, 0, 0);
+    if (B / 2 > 0)
+      hipLaunchKernelGGL(k_shape_solve<32>, dim3(B / 2), dim3(64), 2 * solve_lds(d), st, d, ws, B, beta_reg,
+                         beta_reg2, kid_reg, pair_form, use_ref, mode, 0, 0);
     if (B & 1)
       hipLaunchKernelGGL(k_shape_solve<64>, dim3(1), dim3(64), solve_lds(d), st, d, ws, B, beta_reg, beta_reg2,
                          kid_reg, pair_form, use_ref, mode, B - 1, 0);
@@ -1032,6 +1018,70 @@ void launch_shape_solve(const DevModel& d, const Workspace& ws, int B, hipStream
     hipLaunchKernelGGL(k_shape_solve<64>, dim3(B), dim3(64), solve_lds(d), st, d, ws, B, beta_reg, beta_reg2,
                        kid_reg, pair_form, use_ref, mode, 0, 0);
   }
+}
+
+// K4' (k_solve_bm): the normal-equation combine and the shape solve of the batch-major path as one launch, lane =
+// instance.  Applies to the plain per-instance solve on the sums of k_residual_bm + k_pair_gram_bm (unit vertex weights
+// in the solve, no share_beta, no scale unknown) for 10 / 11 shape unknowns; everything else keeps k_gram_combine_bm +
+// k_shape_solve (SMPLFIT_SOLVE_BM=0: everywhere, A/B).
+constexpr int kSolveIB = 16;
+// what k_solve_bm needs beyond the model: the longest run of moment rows of a joint in the residual table of this batch
+// (rounded up to 8), the sizes of its three buffers (their descriptors take byte offsets below 2^31)
+struct SolveBmPlan {
+  bool ok = false;
+  SolveBmArgs a{};
+  ShareView sv{};
+  size_t lds = 0;
+};
+SolveBmPlan solve_bm_plan(const smplfit_handle* h, int B) {
+  SolveBmPlan p;
+  const DevModel& d = h->d;
+  if (!tune().solve_bm || d.general || !(d.S == 10 || d.S == 11) || !d.bm_tables) return p;
+  const int idx = share_index(sf::kShareResidual, B);
+  if (idx >= sf::kShareFine || (size_t)idx >= h->views.size()) return p;  // (small batches: the fine cell tables keep k_gram_combine_split + k_shape_solve)
+  const sf::ShareTable& t = h->t.shares[idx];
+  const int maxn = h->views[idx].aux_pitch;
+  const size_t Mp = align_up((size_t)B, 128);
+  const size_t res_rows = (size_t)t.ncells * ((d.S + 3 + 3) / 4 * 4) + (size_t)t.nrows * 3 * sf::kGroupJoints;
+  const size_t res_bytes = res_rows * Mp * 4;
+  const size_t gram_bytes = (size_t)pair_gram_workgroups(d.J, d.jt.np) * sf::ne_ng(d.S) * Mp * 4;
+  const size_t jdt_bytes = Mp * align_up((size_t)d.J * sf::jd_stride(d.S), 64) * 4;
+  int lg = 0;
+  while ((8 << lg) < t.ncells) ++lg;
+  if (maxn > kSolveT3 || (8 << lg) != t.ncells || res_bytes >= (1u << 31) || gram_bytes >= (1u << 31) || jdt_bytes >= (1u << 31) ||
+      !h->views[idx].aux_pad)
+    return p;
+  p.sv = share_view(h, sf::kShareResidual, B);
+  const bool stage_px = solve_bm_lds_bytes(d.S, kSolveIB, d.J, t.ncells, maxn, true) <= 156 * 1024;
+  p.lds = solve_bm_lds_bytes(d.S, kSolveIB, d.J, t.ncells, maxn, stage_px);
+  if (p.lds > 156 * 1024) return p;
+  p.a.stage_px = stage_px ? 1 : 0;
+  p.a.maxn = maxn;
+  p.a.lg_ngrp = lg;
+  p.a.res_bytes = (uint32_t)res_bytes;
+  p.a.gram_bytes = (uint32_t)gram_bytes;
+  p.a.jdt_bytes = (uint32_t)jdt_bytes;
+  p.ok = true;
+  return p;
+}
+bool solve_bm_applies(const smplfit_handle* h, int B) { return solve_bm_plan(h, B).ok; }
+template <int S>
+void launch_solve_bm_s(const smplfit_handle* h, const Workspace& ws, int B, hipStream_t st, SolveBmPlan p) {
+  const DevModel& d = h->d;
+  const int Mp = (int)align_up((size_t)B, 128);
+  const int groups = (int)align_up((size_t)Mp / kSolveIB, 32);
+  if (p.lds > 64 * 1024) ensure_max_lds(reinterpret_cast<const void*>(&k_solve_bm<S, kSolveIB>));
+  hipLaunchKernelGGL((k_solve_bm<S, kSolveIB>), dim3(groups), dim3(64 * kSolveWaves), p.lds, st, d, p.sv, ws, B, Mp, p.a);
+}
+void launch_solve_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStream_t st, float beta_reg, float beta_reg2,
+                     float kid_reg, int use_ref) {
+  SolveBmPlan p = solve_bm_plan(h, B);  // (callers ask solve_bm_applies first)
+  p.a.beta_reg = beta_reg;
+  p.a.beta_reg2 = beta_reg2;
+  p.a.kid_reg = kid_reg;
+  p.a.use_ref = use_ref;
+  if (h->d.S == 11) launch_solve_bm_s<11>(h, ws, B, st, p);
+  else launch_solve_bm_s<10>(h, ws, B, st, p);
 }
 
 int post_launch_check() {
@@ -1095,9 +1145,14 @@ int share_sum(const DevModel& d, const Workspace& ws, int B, const FitOptions& o
   return 0;
 }
 
+// fused: the handle when the sums in the workspace are the PARTIAL sums of k_residual_bm + k_pair_gram_bm (the combine
+// was not launched: fused_solve() said so) and k_solve_bm takes them from there; null: the record is in ws.gramv
+bool fused_solve(const smplfit_handle* h, int B, const FitOptions& o, int pair_in, bool scaled) {
+  return pair_in && !scaled && !o.share_beta && solve_bm_applies(h, B);
+}
 int enqueue_solve(const DevModel& d, const Workspace& ws, int B, const FitOptions& o, bool joints, bool eff_v,
                   bool eff_j, const float* jw, int pair_in, int use_ref, bool scaled, hipStream_t st,
-                  bool extras_done = false) {
+                  bool extras_done = false, const smplfit_handle* fused = nullptr) {
   if (d.general && scaled && !tune().gen_mfma)
     return fail(SMPLFIT_ERR_UNSUPPORTED, "general path with SMPLFIT_GEN_MFMA=0: the scale unknown's extra sums come from the "
                                          "matrix-core accumulate kernel only");
@@ -1125,10 +1180,7 @@ int enqueue_solve(const DevModel& d, const Workspace& ws, int B, const FitOption
       sa.b0 = first;
       sa.cen_b0 = cen_b0;
       if (d.general) {
-        static std::once_flag once[16];
-        int dev_id = 0;
-        (void)hipGetDevice(&dev_id);
-        std::call_once(once[dev_id & 15], [] { set_max_lds_once(reinterpret_cast<const void*>(&k_shape_solve_scaled<true>)); });
+        ensure_max_lds(reinterpret_cast<const void*>(&k_shape_solve_scaled<true>));
         hipLaunchKernelGGL(k_shape_solve_scaled<true>, dim3(count), dim3(threads), lds, st, d, ws, sa);
       } else {
         hipLaunchKernelGGL(k_shape_solve_scaled<false>, dim3(count), dim3(64), lds, st, d, ws, sa);
@@ -1146,6 +1198,8 @@ int enqueue_solve(const DevModel& d, const Workspace& ws, int B, const FitOption
     };
     if (int rc = share_sum(d, ws, B, o, st, assemble)) return rc;
     launch_shape_solve(d, ws, B, st, o.beta_reg, o.beta_reg2, o.kid_reg, pair_in, 0, 2);
+  } else if (fused) {
+    launch_solve_bm(fused, ws, B, st, o.beta_reg, o.beta_reg2, o.kid_reg, use_ref);
   } else {
     launch_shape_solve(d, ws, B, st, o.beta_reg, o.beta_reg2, o.kid_reg, pair_in, use_ref);
   }
@@ -1271,7 +1325,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
       launch_jd_transpose(d, ws, B, st);
       if (o.scale_mode && it + 1 == o.num_iter) launch_accum_w_bm(h, ws, B, st, eff_v, true);
       else if (eff_v) launch_accum_w_bm(h, ws, B, st);
-      else launch_residual_bm(h, ws, B, st);
+      else launch_residual_bm(h, ws, B, st, fused_solve(h, B, o, 1, false) ? 3 : 7);  // (k_solve_bm adds the partial sums itself)
     } else {
       launch_gemm(d, ws, B, st);
       if (int rc = launch_accum_any(d, ws, B, eff_v, st, gjr ? tj_rot : nullptr, gjr && eff_j ? jw : nullptr,
@@ -1285,7 +1339,8 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     // record: the classic form of the solve; the residual pass the pair-Gram form)
     const int pair_in = (!eff_v && !d.general && !(bm && scaled_now) && (bm || use_pair_form())) ? 1 : 0;
     if (pb)
-      if (int rc = enqueue_solve(d, ws, B, o, joints, eff_v, eff_j, jw, pair_in, use_ref, scaled_now, st, bm && scaled_now))
+      if (int rc = enqueue_solve(d, ws, B, o, joints, eff_v, eff_j, jw, pair_in, use_ref, scaled_now, st, bm && scaled_now,
+                                 bm && fused_solve(h, B, o, pair_in, scaled_now) ? h : nullptr))
         return rc;
     const bool last = it + 1 == o.num_iter;
     if (last && !o.final_adjust) break;  // nothing consumes the re-evaluated mesh
@@ -1476,7 +1531,7 @@ int launch_convert_source(const ConvertSource& src, const DevModel& d, const Wor
   {
     const ShareView sv = share_view(pl.in, sf::kShareLbsAll, B);
     const dim3 grid = share_grid(sv, Mp);
-    launch_lbs_fwd_bm(di, sv, wi, B, Mp, st);
+    if (int rc_f = launch_lbs_fwd_bm(di, sv, wi, B, Mp, st)) return rc_f;
   }
   TransferTabs tt{pl.d_oslot, pl.d_start, pl.d_islot, pl.d_w, d.V};
   hipLaunchKernelGGL(k_transfer_bm, dim3(pl.nslab, Mp / 64), dim3(256), 0, st, tt, wi.vpT, di.Vp, ws.tT, d.Vp, ws.resP, Mp);
@@ -1849,8 +1904,18 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
           astart[j + 1] = (int32_t)arows.size();
         }
       }
+      sv.max_aux = 0;
+      for (int j = 0; j < t.J; ++j) sv.max_aux = std::max(sv.max_aux, astart[j + 1] - astart[j]);
       up(astart, &sv.aux_start);
       up(arows, &sv.aux_rows);
+      sv.aux_pitch = std::max(16, (sv.max_aux + 15) / 16 * 16);
+      sv.aux_pad = nullptr;
+      if ((int)(i % sf::kShareKinds) == sf::kShareResidual) {
+        std::vector<int32_t> pad((size_t)t.J * sv.aux_pitch, -1);
+        for (int j = 0; j < t.J; ++j)
+          for (int k = astart[j]; k < astart[j + 1]; ++k) pad[(size_t)j * sv.aux_pitch + (k - astart[j])] = arows[k];
+        up(pad, &sv.aux_pad);
+      }
     }
     up(t.brec, &d.brec);
     up(t.pair_E, &d.pair_E);
@@ -2148,7 +2213,7 @@ int smplfit_forward_ex_f32(const smplfit_handle* h, const smplfit_forward_args* 
     launch_jd_transpose(d, ws, batch, st);
     const ShareView sv = share_view(h, sf::kShareLbsAll, batch);
     const dim3 grid = share_grid(sv, Mp);
-    launch_lbs_fwd_bm(d, sv, ws, batch, Mp, st);
+    if (int rc_f = launch_lbs_fwd_bm(d, sv, ws, batch, Mp, st)) return rc_f;
     hipLaunchKernelGGL(k_unlayout_vertices, dim3((d.V + kSlabV - 1) / kSlabV, Mp / 64), dim3(256), (size_t)64 * kSlabRow * 4, st, d,
                        ws.vpT, vertices, batch);
   } else if (vertices) {
@@ -2253,9 +2318,10 @@ int smplfit_shape_solve_ex_f32(const smplfit_handle* h, const smplfit_shape_solv
     launch_jd_transpose(d, ws, batch, st);
     if (scaled) launch_accum_w_bm(h, ws, batch, st, eff_v, true);
     else if (eff_v) launch_accum_w_bm(h, ws, batch, st);
-    else launch_residual_bm(h, ws, batch, st);
-    rc = enqueue_solve(d, ws, batch, o, joints, eff_v, eff_j, joint_weights, (!eff_v && !scaled) ? 1 : 0, use_ref, scaled, st,
-                       scaled);
+    else launch_residual_bm(h, ws, batch, st, fused_solve(h, batch, o, 1, false) ? 3 : 7);
+    const int pair_kp = (!eff_v && !scaled) ? 1 : 0;
+    rc = enqueue_solve(d, ws, batch, o, joints, eff_v, eff_j, joint_weights, pair_kp, use_ref, scaled, st, scaled,
+                       fused_solve(h, batch, o, pair_kp, scaled) ? h : nullptr);
   } else {
     launch_gemm(d, ws, batch, st);
     if (int rc = launch_accum_any(d, ws, batch, eff_v, st, gjr ? ja.tj : nullptr, gjr && eff_j ? joint_weights : nullptr, scaled))
@@ -2276,7 +2342,7 @@ int smplfit_shape_solve_ex_f32(const smplfit_handle* h, const smplfit_shape_solv
   if (args->vertices_out && bm) {  // the mesh at the solution: forward-only LBS pass + the inverse of the target layout
     const ShareView sv = share_view(h, sf::kShareLbsAll, batch);
     const dim3 grid = share_grid(sv, Mp);
-    launch_lbs_fwd_bm(d, sv, ws, batch, Mp, st);
+    if (int rc_f = launch_lbs_fwd_bm(d, sv, ws, batch, Mp, st)) return rc_f;
     hipLaunchKernelGGL(k_unlayout_vertices, dim3((d.V + kSlabV - 1) / kSlabV, Mp / 64), dim3(256), (size_t)64 * kSlabRow * 4, st, d,
                        ws.vpT, args->vertices_out, batch);
   } else if (args->vertices_out) {
@@ -2339,13 +2405,7 @@ int smplfit_transfer_f32(const smplfit_transfer* t, const float* in_vertices, in
   hipStream_t st = (hipStream_t)hip_stream;
   const size_t lds = (size_t)t->v_in * 12;
   if (lds <= 160 * 1024) {
-    static std::once_flag once[16];
-    int dev_id = 0;
-    (void)hipGetDevice(&dev_id);
-    std::call_once(once[dev_id & 15], [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_transfer_rows<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
+    ensure_max_lds(reinterpret_cast<const void*>(&k_transfer_rows<true>));
     hipLaunchKernelGGL(k_transfer_rows<true>, dim3(batch), dim3(1024), lds, st, in_vertices, out_vertices, t->d_indptr,
                        t->d_indices, t->d_values, t->v_in, t->v_out);
   } else {
@@ -2494,7 +2554,9 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
         return 0;
       }
       case SMPLFIT_KERNEL_SHAPE_SOLVE:
-        launch_shape_solve(d, ws, batch, st, 1.0f, 0.0f, 1.0f, use_pair_form() ? 1 : 0, 0);
+        // (the default fit's solve: k_solve_bm on the partial sums the last fit left, else the wave-per-instance stage)
+        if (bm && solve_bm_applies(h, batch)) launch_solve_bm(h, ws, batch, st, 1.0f, 0.0f, 1.0f, 0);
+        else launch_shape_solve(d, ws, batch, st, 1.0f, 0.0f, 1.0f, (bm || use_pair_form()) ? 1 : 0, 0);
         return 0;
       case SMPLFIT_KERNEL_LBS_PARTSUM: {
         if (bm) {
@@ -2539,6 +2601,7 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
       }
       case SMPLFIT_KERNEL_GRAM_COMBINE:
         if (!bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "normal-equation combine: batch-major path not active");
+        if (solve_bm_applies(h, batch)) return fail(SMPLFIT_ERR_UNSUPPORTED, "normal-equation combine: part of k_solve_bm (SMPLFIT_KERNEL_SHAPE_SOLVE)");
         launch_residual_bm(h, ws, batch, st, 4);
         return 0;
       case SMPLFIT_KERNEL_PSUM_COMBINE:
@@ -2572,8 +2635,10 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
   auto pre = [&]() {
     if (nopre) return 0;
     if (kernel_id == SMPLFIT_KERNEL_SHAPE_ACCUM) launch_gemm(d, ws, batch, st, bm);
-    if ((kernel_id == SMPLFIT_KERNEL_LBS_PARTSUM || kernel_id == SMPLFIT_KERNEL_LBS_LAST) && bm)
-      launch_shape_solve(d, ws, batch, st, 1.0f, 0.0f, 1.0f, 1, 0);
+    if ((kernel_id == SMPLFIT_KERNEL_LBS_PARTSUM || kernel_id == SMPLFIT_KERNEL_LBS_LAST) && bm) {
+      if (solve_bm_applies(h, batch)) launch_solve_bm(h, ws, batch, st, 1.0f, 0.0f, 1.0f, 0);
+      else launch_shape_solve(d, ws, batch, st, 1.0f, 0.0f, 1.0f, 1, 0);
+    }
     if (kernel_id == SMPLFIT_KERNEL_LBS_PARTSUM && !bm) {
       if (int rc = launch_accum_any(d, ws, batch, false, st)) return rc;
     }
@@ -2696,6 +2761,14 @@ int smplfit_debug_lds_victim(void* stream, int nwg, int iters, uint32_t* log, in
 int smplfit_debug_wave_stamps(unsigned long long* dst, int n) {
   if (hipDeviceSynchronize() != hipSuccess) return -1;
   return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wave_stamps), (size_t)n * 5 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
+
+#ifdef SMPLFIT_SOLVE_STAMPS
+// debug builds: the phase stamps of the last k_solve_bm launch (n workgroups x 8 values), see kernels_bm.inc
+int smplfit_debug_solve_stamps(unsigned long long* dst, int n) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_solve_stamps), (size_t)n * 8 * 8) == hipSuccess ? 0 : -1;
 }
 #endif
 

@@ -27,6 +27,25 @@ def test_header_symbols_exported(lib):
         assert getattr(lib, s) is not None
 
 
+def test_build_id_covers_csrc():
+    """Every file under csrc/ (and the public header) enters needs_build() and the build id smplfit_version() reports:
+    an edit to any kernel file must change the id the profiles are tied to (round 5: kernels_gen.inc was missing)."""
+    import os
+    import re
+
+    from smplfitter_amd import build as b
+
+    hashed = {os.path.normpath(os.path.join(b.CSRC, f)) for f in b.SOURCES + b._headers()}
+    for f in os.listdir(b.CSRC):
+        assert os.path.normpath(os.path.join(b.CSRC, f)) in hashed, f
+    # every #include "..." of the translation units resolves to a hashed file
+    for src in b.SOURCES:
+        for inc in re.findall(r'^#include "([^"]+)"', open(os.path.join(b.CSRC, src)).read(), re.M):
+            assert os.path.normpath(os.path.join(b.CSRC, inc)) in hashed, (src, inc)
+    assert os.path.normpath(os.path.join(b.CSRC, '../../include/smplfit.h')) in hashed
+    assert re.fullmatch(r'[0-9a-f]{12}', b.source_id())
+
+
 def test_no_device_fails_loudly(lib, model_root):
     import torch
 

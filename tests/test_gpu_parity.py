@@ -203,7 +203,7 @@ def test_fit_goldens(name, model_root, golden, dev, vertex_path):
     kind, md = util.load_md(model_root, name, g)
     om64, _ = util.make_oracle(md, kind, np.float64)
     m, f = get_model(model_root, name, g, dev)
-    if name in util.SKIN_KINDS:  # six weights per vertex: eight (joint, weight) pairs, wave-per-instance kernels only
+    if name in util.SKIN_KINDS:  # six weights per vertex: eight (joint, weight) pairs per vertex — pieces of up to eight joints on the batch-major kernels (round 5); `vertex_path` runs both families
         assert m._native(dev).info.skin_width == (8 if name.endswith('_w6') else 4)
     # pose: 3e-4 on the well-conditioned SMPL fixtures (the host emulation of this arithmetic sits at
     # <= 2.2e-4 on all 32 option combinations; the reference's own fp32 floor is 3e-4); the
@@ -317,6 +317,43 @@ def test_edge_batches(model_root, golden, dev):
         m(pose_rotvecs=torch.zeros(1, 72, device=dev), glob_rotmats=torch.zeros(1, 24, 3, 3, device=dev))
     with pytest.raises(TypeError):
         m(pose_rotvecs=np.zeros((1, 72), np.float32))
+
+
+@pytest.mark.parametrize('name,B', [('smpl', 4096), ('smpl', 37), ('smpl', 1000), ('smplx', 2304), ('smpl1024', 16384)])
+def test_solve_bm_matches_two_kernels(name, B, model_root, golden, dev, smplfit_env):
+    """k_solve_bm (round 6: the normal-equation combine + the shape solve as one kernel, lane = instance) forms every
+    sum in the order of k_gram_combine_bm + sf::solve_stage: its fits must equal the two-kernel path's bit for bit —
+    whole batches (coarse cell tables), small / odd ones (fine tables, a last workgroup of partly idle lanes), with the
+    kid unknown (S = 11), with ridge references (warm start) and through fit_with_known_pose."""
+    from smplfitter_amd.pt import BodyFitter
+
+    g = golden(name)
+    m, f = get_model(model_root, name, g, dev)
+    fk = BodyFitter(m, enable_kid=True)
+    tv, tj = make_targets(m, B, 23, dev, noise=0.003)
+    keys = ['pose_rotvecs', 'shape_betas', 'trans']
+
+    def calls():
+        out = {}
+        out['fit'] = to_np(f.fit(tv, tj, num_iter=3, beta_regularizer=1.0, requested_keys=keys))
+        if name != 'smpl1024':  # (the subset model has no joint regressor over its vertices)
+            out['fit_nojoints'] = to_np(f.fit(tv, None, num_iter=2, beta_regularizer=0.0, final_adjust_rots=False, requested_keys=keys))
+        out['fit_kid'] = to_np(fk.fit(tv, tj, num_iter=2, beta_regularizer=1.0, requested_keys=keys))
+        pose = torch.from_numpy(out['fit']['pose_rotvecs']).to(dev)
+        betas = torch.from_numpy(out['fit']['shape_betas']).to(dev)
+        out['warm'] = to_np(f.fit(tv, tj, num_iter=1, beta_regularizer=0.5, initial_pose_rotvecs=pose,
+                                  initial_shape_betas=betas, requested_keys=keys))
+        out['known_pose'] = to_np(f.fit_with_known_pose(pose, tv, tj, beta_regularizer=1.0))
+        return out
+
+    smplfit_env('SMPLFIT_SOLVE_BM', '0')
+    ref = calls()
+    smplfit_env('SMPLFIT_SOLVE_BM', '1')
+    new = calls()
+    for c in ref:
+        for k in ref[c]:
+            assert np.isfinite(new[c][k]).all(), (c, k)
+            assert np.array_equal(new[c][k], ref[c][k]), (c, k, float(np.abs(new[c][k] - ref[c][k]).max()))
 
 
 def test_stage_half(model_root, golden, dev, smplfit_env):
