@@ -88,8 +88,9 @@ SF_HD double fast_rcp(double x) {
 }
 
 // Nearest rotation in Frobenius norm: R = U diag(1,1,det(UV^T)) V^T of the SVD A = U S V^T
-// (rotation.py:100-110 computes it with a library SVD + reflection fix).  Closed form here, in
-// fp64: cyclic Jacobi on the symmetric M = A^T A gives V and the singular-value order; U's first two
+// (rotation.py:100-110 computes it with a library SVD + reflection fix; rotation.py:26-97 is the reference's own
+// closed form).  Here, in fp64: the closed form through Horn's quaternion eigenproblem (below), and — for the inputs
+// whose nearest rotation is not unique — cyclic Jacobi on the symmetric M = A^T A gives V and the singular-value order; U's first two
 // columns are A v1, A v2 (Gram-Schmidt), and taking u3 = u1 x u2, v3 = v1 x v2 keeps both frames
 // right-handed, which IS the reflection fix (R = u1 v1^T + u2 v2^T + u3 v3^T has det +1).
 // Degenerate inputs: A ~ 0 -> identity; rank 1 -> an arbitrary completion (as any SVD would give).
@@ -117,6 +118,76 @@ SF_HD void proj_so3(const float* Af, float* R) {
   double m11 = a[1] * a[1] + a[4] * a[4] + a[7] * a[7];
   double m12 = a[1] * a[2] + a[4] * a[5] + a[7] * a[8];
   double m22 = a[2] * a[2] + a[5] * a[5] + a[8] * a[8];
+#ifndef SMPLFIT_PROJ_JACOBI_ONLY
+  // ---- closed form (round 6; the north star's "closed-form 3x3 SVD").  The nearest rotation is the rotation of the
+  // unit quaternion q that maximises q^T N q, N = Horn's symmetric 4 x 4 matrix of A (Horn 1987; with A = sum t a^T,
+  // rows = target, Horn's S is A^T).  Its eigenvalues are the signed sums of the singular values, largest
+  // lambda = s1 + s2 + sgn(det A) s3 — the reflection case needs no fix-up: q always is a proper rotation — and the
+  // characteristic polynomial of the trace-free N needs three invariants of the normalised A only:
+  //   P(x) = x^4 - 2 |A|_F^2 x^2 - 8 det(A) x + (2 tr((A^T A)^2) - |A|_F^4),      |A|_F = 1 here.
+  // lambda: Newton from the upper bound sqrt(3) (P is convex and increasing above its largest root: monotone
+  // convergence, 4 steps for the near-rotations of a fit, <= 12 for ill-conditioned inputs); q: a column of
+  // adj(N - lambda I) = P'(lambda) q q^T, the one with the largest diagonal entry.  ~330 fp64 operations without a
+  // data-dependent sweep count, against ~600 for the Jacobi sweeps below, which stay for the inputs whose largest
+  // eigenvalue is (nearly) double — rank 1, or s2 ~ s3 under a reflection: the nearest rotation is not unique there and
+  // the cofactors vanish — detected by |tr adj| = |P'(lambda)| = the product of the gaps to the other eigenvalues.
+  {
+    const double trm2 = (m00 * m00 + m11 * m11 + m22 * m22) + 2.0 * (m01 * m01 + m02 * m02 + m12 * m12);
+    const double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
+    const double c1 = -8.0 * det, c0 = 2.0 * trm2 - 1.0;
+    double lam = 1.7320508075688772;
+    bool conv = false;
+    for (int it = 0; it < 12; ++it) {
+      const double l2 = lam * lam;
+      const double P = (l2 * l2 - 2.0 * l2) + (c1 * lam + c0), dP = 4.0 * (l2 * lam - lam) + c1;
+      if (!(dP > 1e-6)) break;  // (a multiple root at the top: the sweeps below)
+      const double d = P * fast_rcp(dP);
+      lam -= d;
+      if (fabs(d) <= 1e-11 * lam) {  // (quadratic convergence: the step after this one would be below 1e-16)
+        conv = true;
+        break;
+      }
+    }
+    if (conv) {
+      // K = N - lambda I (symmetric), S = A^T:  S_xy = a[3 y + x]
+      const double sxx = a[0], sxy = a[3], sxz = a[6], syx = a[1], syy = a[4], syz = a[7], szx = a[2], szy = a[5], szz = a[8];
+      const double k00 = (sxx + syy + szz) - lam, k01 = syz - szy, k02 = szx - sxz, k03 = sxy - syx;
+      const double k11 = (sxx - syy - szz) - lam, k12 = sxy + syx, k13 = szx + sxz;
+      const double k22 = (-sxx + syy - szz) - lam, k23 = syz + szy;
+      const double k33 = (-sxx - syy + szz) - lam;
+      // adjugate through the 2 x 2 minors of the row pairs (0, 1) and (2, 3)
+      const double s0 = k00 * k11 - k01 * k01, s1 = k00 * k12 - k01 * k02, s2 = k00 * k13 - k01 * k03;
+      const double s3 = k01 * k12 - k11 * k02, s4 = k01 * k13 - k11 * k03, s5 = k02 * k13 - k12 * k03;
+      const double d5 = k22 * k33 - k23 * k23, d4 = k12 * k33 - k13 * k23, d3 = k12 * k23 - k13 * k22;
+      const double d2 = k02 * k33 - k03 * k23, d1 = k02 * k23 - k03 * k22;
+      const double a00 = k11 * d5 - k12 * d4 + k13 * d3, a01 = -k01 * d5 + k02 * d4 - k03 * d3;
+      const double a02 = k13 * s5 - k23 * s4 + k33 * s3, a03 = -k12 * s5 + k22 * s4 - k23 * s3;
+      const double a11 = k00 * d5 - k02 * d2 + k03 * d1, a12 = -k03 * s5 + k23 * s2 - k33 * s1;
+      const double a13 = k02 * s5 - k22 * s2 + k23 * s1, a22 = k03 * s4 - k13 * s2 + k33 * s0;
+      const double a23 = -k02 * s4 + k12 * s2 - k23 * s0, a33 = k02 * s3 - k12 * s1 + k22 * s0;
+      // (the diagonal entries share the sign of P'(lambda); gaps: a well-separated largest eigenvalue)
+      const double tra = fabs((a00 + a11) + (a22 + a33));
+      if (tra > 1e-4) {
+        double q0 = a00, q1 = a01, q2 = a02, q3 = a03, best = fabs(a00);
+        if (fabs(a11) > best) { best = fabs(a11); q0 = a01; q1 = a11; q2 = a12; q3 = a13; }
+        if (fabs(a22) > best) { best = fabs(a22); q0 = a02; q1 = a12; q2 = a22; q3 = a23; }
+        if (fabs(a33) > best) { best = fabs(a33); q0 = a03; q1 = a13; q2 = a23; q3 = a33; }
+        const double qn = fast_rsqrt((q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3));
+        const double w = q0 * qn, x = q1 * qn, y = q2 * qn, z = q3 * qn;
+        R[0] = (float)(1.0 - 2.0 * (y * y + z * z));
+        R[1] = (float)(2.0 * (x * y - w * z));
+        R[2] = (float)(2.0 * (x * z + w * y));
+        R[3] = (float)(2.0 * (x * y + w * z));
+        R[4] = (float)(1.0 - 2.0 * (x * x + z * z));
+        R[5] = (float)(2.0 * (y * z - w * x));
+        R[6] = (float)(2.0 * (x * z - w * y));
+        R[7] = (float)(2.0 * (y * z + w * x));
+        R[8] = (float)(1.0 - 2.0 * (x * x + y * y));
+        return;
+      }
+    }
+  }
+#endif
   // eigenvectors as columns of V (v[r][c])
   double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
 #define SF_JACOBI(app, aqq, apq, arp, arq, vp0, vq0, vp1, vq1, vp2, vq2)                   \
