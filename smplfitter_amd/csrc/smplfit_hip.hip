@@ -272,8 +272,11 @@ void ensure_max_lds(const void* fn) {
 // Work units of k_pair_gram_bm (kernels_bm.inc): every joint twice + chunks of kPgPairs joint pairs; a workgroup of
 // kPgWaves waves takes kPgWaves units and writes ONE upper triangle to ws.gramP.  Shared by the workspace carve, the
 // launch and the combine kernels.
+// (3 pairs per chunk: 77 units = 10 workgroups per instance block for the SMPL-shaped model — 640 workgroups at
+// B = 4096, one round of the chip at 2.5 resident workgroups per CU; with 2 pairs per chunk (rounds 4 - 5) 832: a second,
+// mostly empty round: 27.3 -> 24.7 us, SMPL-X 57 -> 54)
 #ifndef SMPLFIT_PG_PAIRS
-#define SMPLFIT_PG_PAIRS 2
+#define SMPLFIT_PG_PAIRS 3
 #endif
 constexpr int kPgWaves = 8, kPgPairs = SMPLFIT_PG_PAIRS;
 constexpr int pair_gram_units(int J, int npairs) { return 2 * J + (npairs + kPgPairs - 1) / kPgPairs; }

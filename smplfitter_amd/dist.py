@@ -71,6 +71,90 @@ def gather_rows(local_rows: torch.Tensor, total: int, group=None) -> torch.Tenso
     return torch.cat([p[:n] for p, n in zip(parts, sizes)], dim=0)
 
 
+class OverlappedGather:
+    """The result gather of step ``k`` behind the fit of step ``k + 1``.
+
+    A serving / benchmark loop that fits one batch per step needs the gathered rows of a step only after the next step's
+    fit has been enqueued, so the collective does not have to sit on the fit's stream (at 4096 fits per GPU a step is
+    1.5 ms: an 8-rank all-gather issued in line comes straight off the scaling efficiency).  ``submit(parts)`` records an
+    event on the caller's stream — nothing else: no kernel, no wait — and a SIDE stream, behind that event, packs the
+    step's result tensors into one of ``depth`` row buffers and runs ``all_gather_into_tensor`` (RCCL orders the
+    collective after the side stream's work); the caller's stream goes on with the next fit at once.  A buffer is reused
+    ``depth`` steps later, in order on the side stream; the gathered rows of a slot must be consumed before its reuse.  ``result()`` makes the caller's stream wait for the latest collective and
+    returns its ``(world * B, C)`` rows.  CPU tensors (the gloo tests): ``async_op=True`` work handles play the part of
+    the events.  Equal row counts on every rank (the benchmark's weak-scaling layout)."""
+
+    def __init__(self, rows: int, cols: int, dtype=torch.float32, device='cpu', group=None, depth: int = 2):
+        self.group, self.depth, self.k = group, depth, 0
+        self.world = dist.get_world_size(group)
+        self.device = torch.device(device)
+        self.cuda = self.device.type == 'cuda'
+        self.host_staged = self.cuda and dist.get_backend(group) == 'gloo'  # tests on one GPU: no device collective
+        self.send = [torch.empty((rows, cols), dtype=dtype, device=self.device) for _ in range(depth)]
+        self.recv = [torch.empty((self.world * rows, cols), dtype=dtype, device=self.device) for _ in range(depth)]
+        self.work = [None] * depth
+        if self.cuda:
+            self.side = torch.cuda.Stream(device=self.device)
+            self.ready = [torch.cuda.Event() for _ in range(depth)]   # rows of the slot are packed (caller's stream)
+            self.done = [torch.cuda.Event(enable_timing=True) for _ in range(depth)]   # its collective has finished (side stream)
+            self.start = [torch.cuda.Event(enable_timing=True) for _ in range(depth)]
+            self.used = [False] * depth
+
+    def submit(self, parts) -> int:
+        """``parts``: the step's result tensors ``(B, c_i)`` in packing order (or one packed tensor); returns the slot."""
+        s = self.k % self.depth
+        self.k += 1
+        parts = [parts] if isinstance(parts, torch.Tensor) else list(parts)
+        if self.cuda:
+            # the caller's stream only records an event: packing, the wait for the slot's previous collective (in order on
+            # the side stream) and the collective all run on the side stream
+            cur = torch.cuda.current_stream(self.device)
+            self.ready[s].record(cur)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.ready[s])
+                for p in parts:
+                    p.record_stream(self.side)  # (the caching allocator must not hand the fit's outputs out again before the pack has read them)
+                self.start[s].record(self.side)
+                torch.cat(parts, dim=1, out=self.send[s])
+                if self.host_staged:
+                    hg = torch.empty(self.recv[s].shape, dtype=self.recv[s].dtype)
+                    dist.all_gather_into_tensor(hg, self.send[s].cpu(), group=self.group)
+                    self.recv[s].copy_(hg)
+                else:
+                    dist.all_gather_into_tensor(self.recv[s], self.send[s], group=self.group)
+                self.done[s].record(self.side)
+            self.used[s] = True
+        else:
+            if self.work[s] is not None:
+                self.work[s].wait()
+            torch.cat(parts, dim=1, out=self.send[s])
+            self.work[s] = dist.all_gather_into_tensor(self.recv[s], self.send[s], group=self.group, async_op=True)
+        return s
+
+    def result(self, slot: Optional[int] = None) -> torch.Tensor:
+        """The gathered rows of ``slot`` (default: the latest submitted step), valid on the caller's stream."""
+        s = (self.k - 1) % self.depth if slot is None else slot
+        if self.cuda:
+            torch.cuda.current_stream(self.device).wait_event(self.done[s])
+        elif self.work[s] is not None:
+            self.work[s].wait()
+            self.work[s] = None
+        return self.recv[s]
+
+    def gather_ms(self, slot: int) -> float:
+        """HIP-event time of the slot's collective on the side stream (after a device synchronisation)."""
+        return self.start[slot].elapsed_time(self.done[slot]) if self.cuda else 0.0
+
+    def finish(self) -> None:
+        for s in range(self.depth):
+            if self.cuda:
+                if self.used[s]:
+                    self.done[s].synchronize()
+            elif self.work[s] is not None:
+                self.work[s].wait()
+                self.work[s] = None
+
+
 def fit_sharded(fit_fn, target_vertices: torch.Tensor, target_joints: Optional[torch.Tensor],
                 num_joints: int, num_betas: int, group=None, **fit_kwargs) -> dict:
     """Every rank holds the FULL ``(B, V, 3)`` inputs (or generates them); each fits its block with

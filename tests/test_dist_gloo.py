@@ -57,6 +57,47 @@ def test_shard_and_gather_world2(total, tmp_path):
     assert r0['lo'] == 0 and r0['hi'] == r1['lo'] and r1['hi'] == total
 
 
+def _overlap_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from smplfitter_amd import dist as sd
+
+    B, J, S, steps = 5, 24, 10, 7
+    og = sd.OverlappedGather(B, 3 * J + S + 3, device='cpu', depth=2)
+
+    def rows_of(step, r):  # what rank r's fit of `step` returns: three result tensors
+        g = torch.Generator().manual_seed(1000 * step + r)
+        return [torch.randn(B, 3 * J, generator=g), torch.randn(B, S, generator=g), torch.randn(B, 3, generator=g)]
+
+    ok = True
+    prev = None
+    for k in range(steps):
+        slot = og.submit(rows_of(k, rank))   # step k's gather is in flight ...
+        if prev is not None:                 # ... while step k - 1's rows are consumed
+            pk, pslot = prev
+            got = og.result(pslot)
+            want = torch.cat([torch.cat(rows_of(pk, r), dim=1) for r in range(world)], dim=0)
+            ok = ok and torch.equal(got, want)
+        prev = (k, slot)
+    got = og.result()
+    want = torch.cat([torch.cat(rows_of(steps - 1, r), dim=1) for r in range(world)], dim=0)
+    ok = ok and torch.equal(got, want)
+    og.finish()
+    torch.save(dict(ok=bool(ok)), os.path.join(tmp, f'o{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_gather_world2(tmp_path):
+    """The double-buffered result gather of bench.py --gpus N (dist.OverlappedGather): step k's all-gather in flight while
+    step k + 1 packs its rows; every step's gathered rows are the ranks' rows of THAT step, in rank order."""
+    port = 29500 + (os.getpid() % 1000) + 77
+    mp.spawn(_overlap_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert torch.load(tmp_path / 'o0.pt')['ok'] and torch.load(tmp_path / 'o1.pt')['ok']
+
+
 def _share_worker(rank, world, port, root, tmp):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))

@@ -578,8 +578,8 @@ def test_bench_refuses_missing_devices():
 
 def test_bench_world1_rccl_gather(model_root):
     """The RCCL leg of bench.py with ONE rank (`--collective-always`): a world-1 nccl process group, the packed result
-    rows all-gathered by `all_gather_into_tensor` on the fit's stream after every step — the same call, on the same
-    stream, that N ranks make over xGMI (the box has one GPU: this is the part of the collective path that can run here)."""
+    rows of every step all-gathered by `all_gather_into_tensor` — the same call N ranks make over xGMI (the box has one
+    GPU: this is the part of the collective path that can run here)."""
     env = dict(os.environ, SMPLFIT_SYNTH_ROOT=model_root)
     cmd = [sys.executable, 'bench.py', '--steps', '2', '--warmup', '1', '--batch', '512', '--no-cpu-baseline',
            '--collective-always']
@@ -588,5 +588,10 @@ def test_bench_world1_rccl_gather(model_root):
     assert p.returncode == 0 and len(lines) == 1, p.stdout[-2000:] + p.stderr[-3000:]
     out = json.loads(lines[0])
     assert out['n_gpus'] == 1 and out['nccl_world_size'] == 1 and out['value'] > 0
-    assert out['collective'].startswith('nccl all_gather_into_tensor')
+    assert out['collective'].startswith('nccl all_gather_into_tensor') and 'side stream' in out['collective']
     assert out['roofline']['stream_bytes_per_launch'] and out['roofline']['frac_of_section8d_bytes'] > 0
+    # round 6: the gather of step k runs behind the fit of step k + 1 (dist.OverlappedGather); the line carries the same
+    # steps with the gather in line and without any collective beside the headline
+    mg = out['multi_gpu']
+    assert mg['gather'].startswith('overlapped') and mg['ms_per_step_no_collective'] > 0 and mg['ms_per_step_gather_inline'] > 0
+    assert out['ms_per_step'] < 1.5 * mg['ms_per_step_no_collective']  # (2 steps of a small batch: a loose bound)
