@@ -119,6 +119,14 @@ class TorchFit:
 
     # constants on the device of the call (the model's buffers follow .to() / .cuda())
     def _consts(self, device):
+        key = (str(device), self.bm.v_template.data_ptr())  # (rebuilt when the model's buffers move)
+        if getattr(self, '_consts_key', None) == key:
+            return self._consts_val
+        self._consts_val = self._build_consts(device)
+        self._consts_key = key
+        return self._consts_val
+
+    def _build_consts(self, device):
         bm = self.bm
         c = {k: getattr(bm, k).to(device) for k in ('v_template', 'shapedirs', 'posedirs', 'weights', 'J_template',
                                                     'J_shapedirs', 'J_regressor_post_lbs', 'kid_shapedir', 'kid_J_shapedir')}

@@ -158,6 +158,12 @@ class BodyFitter(nn.Module):
             raise NotImplementedError(f'the differentiable fit does not implement {", ".join(bad)}; detach the inputs to use the HIP path')
         if self._torchfit is None:
             self._torchfit = TorchFit(bm, enable_kid=self.enable_kid)
+            # said once per fitter: a caller that feeds network outputs in training mode without detach() lands here
+            import warnings
+
+            warnings.warn('smplfitter_amd: inputs of BodyFitter.fit require gradients — this call runs the PyTorch '
+                          'restatement (pt/_autograd.py), hundreds of times slower than the HIP kernels; detach() the '
+                          'inputs or call under torch.no_grad() unless the gradients are wanted', RuntimeWarning, stacklevel=3)
         mv = lambda t: None if t is None else t.to(device)  # noqa: E731
         return self._torchfit.fit(mv(target_vertices), mv(target_joints), mv(vertex_weights), mv(joint_weights),
                                   num_iter=int(num_iter), beta_regularizer=float(beta_regularizer),
@@ -268,6 +274,11 @@ class BodyFitter(nn.Module):
             raise ValueError('share_beta_group needs share_beta=True')
         if kid_regularizer_reference is not None and not self.enable_kid:
             kid_regularizer_reference = None  # the reference only reads it with enable_kid (:1235-1246)
+        if torch.is_grad_enabled() and any(t is not None and isinstance(t, torch.Tensor) and t.requires_grad for t in
+                                          (pose_rotvecs, target_vertices, target_joints, vertex_weights, joint_weights)):
+            # (as fit_with_known_shape: never a silently non-differentiable result)
+            raise NotImplementedError('fit_with_known_pose on the HIP path is not differentiable: detach the inputs '
+                                      '(or call it under torch.no_grad())')
         bm = self.body_model
         B = target_vertices.shape[0]
         pose = pose_rotvecs.reshape(B, bm.num_joints * 3)

@@ -104,7 +104,8 @@ class BodyModel(nn.Module):
         ``'batch-major'`` (<= 8 skinning weights per vertex, <= 16 betas: the rates of the benchmark configurations),
         ``'wave-per-instance'`` (small vertex subsets, non-normalised weights: about 0.4 x the rate) or
         ``'general'`` (any other ``num_betas`` — e.g. the default ``None``: every column of the file — or more than eight
-        weights per vertex: run-time loops, a correctness path).  No counterpart in the reference."""
+        weights per vertex: run-time loops, a correctness path whose per-call workspace holds an S x S fp64 system per
+        instance — about 1.7 MB per instance at 300 betas).  No counterpart in the reference."""
         device = self.v_template.device if device is None else torch.device(device)
         return ('wave-per-instance', 'batch-major', 'general')[int(self._native(device, kid=enable_kid).info.vertex_path)]
 

@@ -112,6 +112,8 @@ def test_general_goldens(kind, mfma, model_root, golden, dev, smplfit_env):
         keys = ['pose_rotvecs', 'shape_betas', 'trans'] + (['kid_factor'] if c.get('kid') else [])
         o = to_np(fitters[c.get('kid', False)].fit(t(tv, dev), requested_keys=keys, **kw))
         util.check_general(om64, gg, kind, case, o)
+        if mfma == '1' and case == 'it3_reg1_j_nw_fa':  # the fp64 arbiter on the default fit (one case: the oracle forms the dense design matrix)
+            util.general_arbiter(om64, gg, kind, case, o)
         ref = gg[f'{kind}.fit.{case}.pose_rotvecs']
         assert np.abs(o['pose_rotvecs'] - ref).max() < 1e-3, (kind, case)
     # the reference's quick-start conversion (README.md:105-116): both models built without num_betas; same topology here

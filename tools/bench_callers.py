@@ -47,3 +47,29 @@ timeit('fit joints omitted (num_iter=3)', lambda: f.fit(fw['vertices'], None, nu
 timeit('fit weighted (num_iter=3)', lambda: f.fit(fw['vertices'], fw['joints'], vertex_weights=torch.ones(B, 6890, device=dev), joint_weights=torch.ones(B, 24, device=dev), num_iter=3))
 timeit('fit_with_known_shape (num_iter=3)', lambda: f.fit_with_known_shape(betas, fw['vertices'], fw['joints'], num_iter=3))
 timeit('fit_with_known_pose', lambda: f.fit_with_known_pose(pose, fw['vertices'], fw['joints']))
+
+# the differentiable fit (inputs that require gradients: the PyTorch restatement pt/_autograd.py, NOT the HIP path —
+# recorded so that nobody mistakes one for the other); forward + backward of a scalar loss, batch 256
+import warnings
+
+warnings.simplefilter('ignore', RuntimeWarning)
+Bg = 256
+tvg = fw['vertices'][:Bg].clone().requires_grad_(True)
+tjg = fw['joints'][:Bg].clone()
+
+
+def grad_step():
+    r = f.fit(tvg, tjg, num_iter=3, beta_regularizer=1.0, requested_keys=['pose_rotvecs', 'shape_betas', 'trans'])
+    (r['shape_betas'].square().sum() + r['trans'].sum()).backward()
+    tvg.grad = None
+
+
+for _ in range(2):
+    grad_step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(3):
+    grad_step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 3
+print(f'fit with gradients (PyTorch restatement, forward + backward, num_iter=3): {dt*1e3:.1f} ms per {Bg}, {Bg/dt:,.0f} /s', flush=True)

@@ -3,7 +3,7 @@
 """
 import csv, json, os, re, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r06'
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O, F, P = f'{R}/gpurun_out/prof_{tag}/out', f'{R}/gpurun_out/final_{tag}', f'{R}/profiles'
 shutil.copy(f'{O}/pmc_traffic.json', f'{P}/pmc_traffic.json')
@@ -18,16 +18,19 @@ for n in ('bench_skin.json', 'bench_general.json', 'kstats_general.txt', 'pmc_ge
     if os.path.exists(f'{F}/{n}'):
         shutil.copy(f'{F}/{n}', f'{P}/{tag}_{n}')
 build = json.load(open(f'{P}/{tag}_bench_c3.json'))['build']
-rows = list(csv.DictReader(open(f'{F}/kernel_stats_c3.csv')))
-with open(f'{P}/{tag}_kernel_stats_c3.csv', 'w') as f:
-    f.write('# rocprofv3 --kernel-trace --stats of `python bench.py --config c3 --steps 10 --warmup 3 --no-cpu-baseline` '
-            f'(SMPL-X-shaped model, 4096 instances, SMPLFIT_CHUNKS=1: 4096-instance launches), build "{build}"\n')
-    f.write('kernel,calls,total_us,avg_us,min_us,max_us,percent\n')
-    for r in rows:
-        m = re.search(r'(k_[a-z_0-9]+)', r['Name'])
-        k = m.group(1) if m else r['Name'][:60].replace(',', ';')
-        f.write(f"{k},{r['Calls']},{float(r['TotalDurationNs'])/1e3:.1f},{float(r['AverageNs'])/1e3:.2f},"
-                f"{float(r['MinNs'])/1e3:.2f},{float(r['MaxNs'])/1e3:.2f},{float(r['Percentage']):.2f}\n")
+shutil.copy(f'{F}/kernel_stats_c3.csv', f'{P}/{tag}_kernel_stats_c3.csv')  # (windowed on the box: tools/profile_collect.py --window)
+for n in ('solve_stamps.txt', 'solve_ab_time.txt', 'overlap_probe.txt', 'general_path_parity.txt'):
+    if os.path.exists(f'{F}/{n}'):
+        shutil.copy(f'{F}/{n}', f'{P}/{tag}_{n}')
+if os.path.exists(f'{F}/bench_collective.json'):
+    lines = [ln for ln in open(f'{F}/bench_collective.json') if ln.startswith('{')]
+    open(f'{P}/{tag}_bench_collective.json', 'w').write(lines[0])
+# the windowed c3 statistics against the bench line's HIP-event time of the GEMM (review item: within 10 %)
+c3 = json.load(open(f'{P}/{tag}_bench_c3.json'))
+for r in csv.DictReader(ln for ln in open(f'{P}/{tag}_kernel_stats_c3.csv') if not ln.startswith('#')):
+    if r['kernel'].startswith('k_posedirs_gemm'):
+        ev = c3['roofline'].get('kernel_ms', {}).get('posedirs_gemm')
+        print('c3 GEMM: rocprofv3 avg', r['avg_us'], 'us, HIP events', None if ev is None else round(ev * 1e3, 1), 'us')
 d = json.load(open(f'{R}/gpurun_out/pmc_sq_{tag}_smplx.json'))
 g = d['k_posedirs_gemm_bf16x3_tiled']
 cyc = g['GRBM_GUI_ACTIVE'] / 8

@@ -6,10 +6,12 @@
 Usage: python tools/profile_collect.py gpurun_out/prof_<tag> <tag>"""
 import collections, csv, glob, json, os, re, sys
 
-src, tag = sys.argv[1], sys.argv[2]
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DST = os.path.join(src, 'out')  # gpurun merges gpurun_out/ back; copy DST/* into profiles/ afterwards
-os.makedirs(DST, exist_ok=True)
+WINDOW = sys.argv[1] == '--window'  # python tools/profile_collect.py --window <trace dir> <out.csv> "<header>" [chunks]
+if not WINDOW:
+    src, tag = sys.argv[1], sys.argv[2]
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    DST = os.path.join(src, 'out')  # gpurun merges gpurun_out/ back; copy DST/* into profiles/ afterwards
+    os.makedirs(DST, exist_ok=True)
 
 
 def short(n):
@@ -61,6 +63,12 @@ def stats_csv(rows, path, head, chunks, warm=3):
     return (f'{os.path.basename(path)}: {nfit} fits, span {span/1e6:.2f} ms ({span/1e3/nfit:.1f} us per fit), kernel time summed '
             f'{tot/1e3:.2f} ms ({tot/nfit:.1f} us per fit), >= 1 kernel in flight {100*b1/span:.1f} %, >= 2 kernels {100*b2/span:.1f} %')
 
+
+if WINDOW:
+    # the same window for any traced `bench.py --steps 10 --warmup 3` command (round 6: the SMPL-X configuration —
+    # round 5's c3 file came straight from rocprofv3 --stats and averaged warm-up and target synthesis in)
+    print(stats_csv(trace_rows(sys.argv[2]), sys.argv[3], sys.argv[4], int(sys.argv[5]) if len(sys.argv) > 5 else 1))
+    sys.exit(0)
 
 bench = json.load(open(f'{src}/bench_chunks1.json'))  # build id / configuration (the default line is measured after this script)
 build = bench['build']
