@@ -233,7 +233,11 @@ SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
                        const float* tjc, const float* rj_in, const float* Gprev, const float* jw,
                        bool fit_rotations, bool do_prologue, bool joint_block,
                        bool joint_block_weighted, bool vertex_sa_closed_form, float* Gout,
-                       float* rp_out, float* jd_out, float* pext_out, float* gramj_out) {
+                       float* rp_out, float* jd_out, float* pext_out, float* gramj_out,
+                       float* GT_out = nullptr, int gt_pitch = 0) {
+  // GT_out (round 6): the instance's column of an instance-innermost copy of G — element (j, k) at
+  // GT_out[(j * 9 + k) * gt_pitch] — for the batch-major prologue kernel k_prologue_bm, which then follows instead of
+  // the prologue below (do_prologue = false)
   const int J = tb.J, S = tb.S, S1 = S + 1;
   SF_STAMP(0);
   SF_FOR(k, J * 3) {
@@ -245,6 +249,7 @@ SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
     SF_FOR(k, J * 9) {
       sh.G[k] = Gprev[k];
       Gout[k] = Gprev[k];
+      if (GT_out) GT_out[k * gt_pitch] = Gprev[k];
     }
   }
   SF_FOR(j, J) {
@@ -312,6 +317,7 @@ SF_HD void joint_stage(Ctx& cx, const JointTabs& tb, const JointScratch& sh, con
     for (int k = 0; k < 9; ++k) {
       sh.G[j * 9 + k] = G[k];
       Gout[j * 9 + k] = G[k];
+      if (GT_out) GT_out[(j * 9 + k) * gt_pitch] = G[k];
     }
   }
   cx.sync();

@@ -82,6 +82,8 @@ struct DevModel {
   const float* sdg;        // (Vp, 3, S4) shapedirs, vertex-major, rows padded to a multiple of four
   const int32_t* segall;   // (nsegall, 3) part-aligned tiles over every slot
   int nsegall;
+  // k_prologue_bm: the ancestors of every joint from the root down (CSR; the joint itself excluded)
+  const int32_t *anc_start, *anc;
 };
 
 // One cell table on the device (sf::ShareTable) as the kernels take it, with the multiplier a launch picked.
@@ -250,6 +252,10 @@ struct Workspace {
   // general path: the S-sized scratch of the per-instance stages lives here instead of LDS
   float* gT;       // (B,J,3,S+1) T = P - G J_ext of the joint stage (its P is ws.pext)
   float* gsolve;   // (B, gen_solve_scratch_floats(S)) the scratch of stage S / S' (the S x S system)
+  // batch-major prologue (k_prologue_bm, round 6)
+  float* GT;       // (J*9, Mp) global rotations, instance-innermost (written by k_joint_stage beside ws.G)
+  float* pextT;    // (J*3*(S+1), Mp) FK positions with their beta-Jacobian, instance-innermost
+  float* gramjP;   // (prologue workgroups per instance block, NE+1, Mp) partial sums of the joint block
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -281,6 +287,8 @@ void ensure_max_lds(const void* fn) {
 constexpr int kPgWaves = 8, kPgPairs = SMPLFIT_PG_PAIRS;
 constexpr int pair_gram_units(int J, int npairs) { return 2 * J + (npairs + kPgPairs - 1) / kPgPairs; }
 constexpr int pair_gram_workgroups(int J, int npairs) { return (pair_gram_units(J, npairs) + kPgWaves - 1) / kPgWaves; }
+constexpr int kProWaves = 8;  // joints (= waves) per workgroup of k_prologue_bm
+constexpr int prologue_splits(int J) { return (J + kProWaves - 1) / kProWaves; }
 constexpr int kAccExtrasHost = 16;  // (= kAccExtras of kernels_bm.inc: the extras of the scaled solve behind a cell record)
 
 #ifndef SMPLFIT_SLAB
@@ -369,6 +377,10 @@ size_t carve(const sf::HostTables& t, int B, char* base, Workspace* w, bool fwd_
   ws.jdT = (float*)take(t.general ? 0 : Mp * align_up((size_t)J * sf::jd_stride(S), 64) * 4, true);
   ws.gT = (float*)take(t.general ? (size_t)B * J * 3 * (S + 1) * 4 : 0, true);
   ws.gsolve = (float*)take(t.general ? (size_t)B * align_up((size_t)sf::gen_solve_scratch_floats((int)S), 4) * 4 : 0);
+  const bool pro = !t.general && !t.shares.empty();  // (the models the batch-major path can serve)
+  ws.GT = (float*)take(pro ? Mp * J * 9 * 4 : 0);
+  ws.pextT = (float*)take(pro ? Mp * J * 3 * (S + 1) * 4 : 0);
+  ws.gramjP = (float*)take(pro ? (size_t)prologue_splits((int)J) * NE1 * Mp * 4 : 0);
   if (w) *w = ws;
   return off;
 }
@@ -429,6 +441,7 @@ struct Tuning {
   int bm_slots = 4096;     // SMPLFIT_BM_SLOTS: resident waves a batch-major vertex pass is dealt for (share-count choice)
   int gen_flush = 0;       // SMPLFIT_GEN_FLUSH: vertices between two fp64 additions of the general accumulate kernel's fp32 sums (0: 2048; a scaled iteration: every blend pass)
   bool gen_mfma = true;    // SMPLFIT_GEN_MFMA=0: the general path's vertex block on the vector ALUs (k_gen_accum) instead of the matrix cores (A/B)
+  bool prologue_bm = true; // SMPLFIT_PROLOGUE_BM=0: the shape prologue inside k_joint_stage + the joint-row transpose instead of k_prologue_bm (A/B)
   bool solve_bm = true;    // SMPLFIT_SOLVE_BM=0: normal-equation combine + wave-per-instance solve as two launches instead of k_solve_bm (A/B)
   int bm_lds_kb = 0;       // SMPLFIT_BM_LDS_KB: LDS request of the two batch-major vertex passes padded to this (54: three
                            // workgroups per CU instead of four, which leaves registers / LDS for another chunk's small kernels)
@@ -460,6 +473,7 @@ Tuning read_tuning() {
   if (const char* e = env("SMPLFIT_GEN_MFMA")) t.gen_mfma = e[0] != '0';
   if (const char* e = env("SMPLFIT_GEN_FLUSH")) t.gen_flush = std::max(atoi(e), 0);
   if (const char* e = env("SMPLFIT_SOLVE_BM")) t.solve_bm = e[0] != '0';
+  if (const char* e = env("SMPLFIT_PROLOGUE_BM")) t.prologue_bm = e[0] != '0';
   if (const char* e = env("SMPLFIT_BM_LDS_KB")) t.bm_lds_kb = std::min(std::max(atoi(e), 0), 64);
   return t;
 }
@@ -1076,15 +1090,50 @@ void launch_solve_bm_s(const smplfit_handle* h, const Workspace& ws, int B, hipS
   if (p.lds > 64 * 1024) ensure_max_lds(reinterpret_cast<const void*>(&k_solve_bm<S, kSolveIB>));
   hipLaunchKernelGGL((k_solve_bm<S, kSolveIB>), dim3(groups), dim3(64 * kSolveWaves), p.lds, st, d, p.sv, ws, B, Mp, p.a);
 }
+// pro: the joint block and the FK rows come from k_prologue_bm (ws.gramjP, ws.pextT) instead of k_joint_stage
 void launch_solve_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStream_t st, float beta_reg, float beta_reg2,
-                     float kid_reg, int use_ref) {
+                     float kid_reg, int use_ref, bool pro = false) {
   SolveBmPlan p = solve_bm_plan(h, B);  // (callers ask solve_bm_applies first)
+  p.a.gj_parts = pro ? prologue_splits(h->d.J) : 0;
+  p.a.pext_t = pro ? 1 : 0;
   p.a.beta_reg = beta_reg;
   p.a.beta_reg2 = beta_reg2;
   p.a.kid_reg = kid_reg;
   p.a.use_ref = use_ref;
   if (h->d.S == 11) launch_solve_bm_s<11>(h, ws, B, st, p);
   else launch_solve_bm_s<10>(h, ws, B, st, p);
+}
+
+// K1p (k_prologue_bm): the shape prologue of the joint stage on the batch-major path — k_joint_stage then fits the
+// rotations only and leaves ws.GT.  Applies when every shape solve of the call is k_solve_bm (the one consumer of its
+// ws.gramjP / ws.pextT): the plain per-instance solve, unit vertex weights in the solve, 10 / 11 unknowns.
+bool prologue_bm_applies(const smplfit_handle* h, int B) { return tune().prologue_bm && solve_bm_applies(h, B); }
+void launch_prologue_bm(const smplfit_handle* h, const JointStageArgs& ja, const Workspace& ws, int B, hipStream_t st) {
+  const DevModel& d = h->d;
+  const int Mp = (int)align_up((size_t)B, 128);
+  PrologueArgs pa{ja.tj, ja.jw, ja.joint_block, ja.joint_block_weighted, ja.vertex_sa_closed_form, B};
+  const size_t lds = (size_t)(kProWaves / 2) * (sf::ne_size(d.S) + 1) * 64 * 4;
+  const dim3 grid(Mp / 64, prologue_splits(d.J));
+  if (d.S == 11) {
+    if (lds > 64 * 1024) ensure_max_lds(reinterpret_cast<const void*>(&k_prologue_bm<11>));
+    hipLaunchKernelGGL(k_prologue_bm<11>, grid, dim3(64 * kProWaves), lds, st, d, pa, ws, Mp);
+  } else {
+    if (lds > 64 * 1024) ensure_max_lds(reinterpret_cast<const void*>(&k_prologue_bm<10>));
+    hipLaunchKernelGGL(k_prologue_bm<10>, grid, dim3(64 * kProWaves), lds, st, d, pa, ws, Mp);
+  }
+}
+// the joint stage of a fit on the batch-major path: rotations by k_joint_stage, the prologue by k_prologue_bm (pro), or
+// both by k_joint_stage
+void launch_joint_stage_fit(const smplfit_handle* h, JointStageArgs ja, const Workspace& ws, int B, hipStream_t st, bool pro) {
+  if (pro && ja.do_prologue) {
+    ja.do_prologue = 0;
+    ja.gt_pitch = (int)align_up((size_t)B, 128);
+    launch_joint_stage(h->d, ja, ws, B, st);
+    ja.do_prologue = 1;
+    launch_prologue_bm(h, ja, ws, B, st);
+  } else {
+    launch_joint_stage(h->d, ja, ws, B, st);
+  }
 }
 
 int post_launch_check() {
@@ -1155,7 +1204,7 @@ bool fused_solve(const smplfit_handle* h, int B, const FitOptions& o, int pair_i
 }
 int enqueue_solve(const DevModel& d, const Workspace& ws, int B, const FitOptions& o, bool joints, bool eff_v,
                   bool eff_j, const float* jw, int pair_in, int use_ref, bool scaled, hipStream_t st,
-                  bool extras_done = false, const smplfit_handle* fused = nullptr) {
+                  bool extras_done = false, const smplfit_handle* fused = nullptr, bool pro = false) {
   if (d.general && scaled && !tune().gen_mfma)
     return fail(SMPLFIT_ERR_UNSUPPORTED, "general path with SMPLFIT_GEN_MFMA=0: the scale unknown's extra sums come from the "
                                          "matrix-core accumulate kernel only");
@@ -1202,7 +1251,7 @@ int enqueue_solve(const DevModel& d, const Workspace& ws, int B, const FitOption
     if (int rc = share_sum(d, ws, B, o, st, assemble)) return rc;
     launch_shape_solve(d, ws, B, st, o.beta_reg, o.beta_reg2, o.kid_reg, pair_in, 0, 2);
   } else if (fused) {
-    launch_solve_bm(fused, ws, B, st, o.beta_reg, o.beta_reg2, o.kid_reg, use_ref);
+    launch_solve_bm(fused, ws, B, st, o.beta_reg, o.beta_reg2, o.kid_reg, use_ref, pro);
   } else {
     launch_shape_solve(d, ws, B, st, o.beta_reg, o.beta_reg2, o.kid_reg, pair_in, use_ref);
   }
@@ -1307,7 +1356,9 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     ja.rj = ws.rjreg;
     ja.rj_shared = 1;
   }
-  if (on(0)) launch_joint_stage(d, ja, ws, B, st);
+  // (every solve of this call is k_solve_bm: the prologue runs as k_prologue_bm, which also writes ws.jdT)
+  const bool pro = bm && !o.rotations_only && !eff_v && !o.scale_mode && !o.share_beta && prologue_bm_applies(h, B);
+  if (on(0)) launch_joint_stage_fit(h, ja, ws, B, st, pro);
   if (o.rotations_only) {
     if (on(0)) hipLaunchKernelGGL(k_copy, dim3(256), dim3(256), 0, st, ws.G, orient, (size_t)B * d.J * 9);
     return post_launch_check();
@@ -1325,7 +1376,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
       // not kept: k_joint_stage writing ws.jdT itself — 64 waves of one XCD completing every 256-byte row with
       // one float each — instead of this 8 us launch: 2.54 -> 2.50 M fits/s, SMPL-X 1.31 -> 1.24: the scattered
       // stores cost the latency-bound stage more than the transpose.)
-      launch_jd_transpose(d, ws, B, st);
+      if (!pro) launch_jd_transpose(d, ws, B, st);
       if (o.scale_mode && it + 1 == o.num_iter) launch_accum_w_bm(h, ws, B, st, eff_v, true);
       else if (eff_v) launch_accum_w_bm(h, ws, B, st);
       else launch_residual_bm(h, ws, B, st, fused_solve(h, B, o, 1, false) ? 3 : 7);  // (k_solve_bm adds the partial sums itself)
@@ -1343,7 +1394,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     const int pair_in = (!eff_v && !d.general && !(bm && scaled_now) && (bm || use_pair_form())) ? 1 : 0;
     if (pb)
       if (int rc = enqueue_solve(d, ws, B, o, joints, eff_v, eff_j, jw, pair_in, use_ref, scaled_now, st, bm && scaled_now,
-                                 bm && fused_solve(h, B, o, pair_in, scaled_now) ? h : nullptr))
+                                 bm && fused_solve(h, B, o, pair_in, scaled_now) ? h : nullptr, pro))
         return rc;
     const bool last = it + 1 == o.num_iter;
     if (last && !o.final_adjust) break;  // nothing consumes the re-evaluated mesh
@@ -1362,7 +1413,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     ja.rj = joints ? ws.rjoints : ws.rjreg;
     ja.rj_shared = 0;
     ja.Gprev = ws.G;
-    if (pb) launch_joint_stage(d, ja, ws, B, st);
+    if (pb) launch_joint_stage_fit(h, ja, ws, B, st, pro);
   }
   if (!on(1 + 2 * o.num_iter)) return post_launch_check();
   RefineArgs ra{};
@@ -1924,6 +1975,21 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
     up(t.pair_E, &d.pair_E);
     up(t.jn_start, &d.jn_start);
     up(t.jn, &d.jn);
+    {  // ancestors of every joint, root first (k_prologue_bm walks them: the level-by-level FK as a sum along the chain)
+      std::vector<int32_t> as(t.J + 1, 0), an;
+      for (int j = 0; j < t.J; ++j) {
+        std::vector<int32_t> ch;
+        for (int a2 = j; a2 > 0;) {
+          a2 = t.parents[a2];
+          ch.push_back(a2);
+        }
+        an.insert(an.end(), ch.rbegin(), ch.rend());
+        as[j + 1] = (int32_t)an.size();
+      }
+      if (an.empty()) an.push_back(0);
+      up(as, &d.anc_start);
+      up(an, &d.anc);
+    }
     up(t.pair_c2e, &d.pair_c2e);
     up(t.diag_c2e, &d.diag_c2e);
   }
@@ -2558,7 +2624,7 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
       }
       case SMPLFIT_KERNEL_SHAPE_SOLVE:
         // (the default fit's solve: k_solve_bm on the partial sums the last fit left, else the wave-per-instance stage)
-        if (bm && solve_bm_applies(h, batch)) launch_solve_bm(h, ws, batch, st, 1.0f, 0.0f, 1.0f, 0);
+        if (bm && solve_bm_applies(h, batch)) launch_solve_bm(h, ws, batch, st, 1.0f, 0.0f, 1.0f, 0, prologue_bm_applies(h, batch));
         else launch_shape_solve(d, ws, batch, st, 1.0f, 0.0f, 1.0f, (bm || use_pair_form()) ? 1 : 0, 0);
         return 0;
       case SMPLFIT_KERNEL_LBS_PARTSUM: {
@@ -2583,7 +2649,8 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
         ja.joint_block = gen_joint_rows(d) ? 0 : 1;
         ja.joint_block_weighted = 0;
         ja.vertex_sa_closed_form = d.general ? 0 : 1;
-        launch_joint_stage(d, ja, ws, batch, st);
+        // (what a default fit runs: the rotations + k_prologue_bm where that applies)
+        launch_joint_stage_fit(h, ja, ws, batch, st, bm && prologue_bm_applies(h, batch));
         return 0;
       }
       case SMPLFIT_KERNEL_REFINE: {  // (outputs into the workspace: ws.tvs is unused between fits)
@@ -2613,6 +2680,7 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
         return 0;
       case SMPLFIT_KERNEL_JD_TRANSPOSE:
         if (!bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "joint-row transpose: batch-major path not active");
+        if (prologue_bm_applies(h, batch)) return fail(SMPLFIT_ERR_UNSUPPORTED, "joint-row transpose: k_prologue_bm writes ws.jdT itself");
         launch_jd_transpose(d, ws, batch, st);
         return 0;
       case SMPLFIT_KERNEL_MEAN_FINISH:
@@ -2639,7 +2707,7 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
     if (nopre) return 0;
     if (kernel_id == SMPLFIT_KERNEL_SHAPE_ACCUM) launch_gemm(d, ws, batch, st, bm);
     if ((kernel_id == SMPLFIT_KERNEL_LBS_PARTSUM || kernel_id == SMPLFIT_KERNEL_LBS_LAST) && bm) {
-      if (solve_bm_applies(h, batch)) launch_solve_bm(h, ws, batch, st, 1.0f, 0.0f, 1.0f, 0);
+      if (solve_bm_applies(h, batch)) launch_solve_bm(h, ws, batch, st, 1.0f, 0.0f, 1.0f, 0, prologue_bm_applies(h, batch));
       else launch_shape_solve(d, ws, batch, st, 1.0f, 0.0f, 1.0f, 1, 0);
     }
     if (kernel_id == SMPLFIT_KERNEL_LBS_PARTSUM && !bm) {

@@ -19,7 +19,7 @@ for n in ('bench_skin.json', 'bench_general.json', 'kstats_general.txt', 'pmc_ge
         shutil.copy(f'{F}/{n}', f'{P}/{tag}_{n}')
 build = json.load(open(f'{P}/{tag}_bench_c3.json'))['build']
 shutil.copy(f'{F}/kernel_stats_c3.csv', f'{P}/{tag}_kernel_stats_c3.csv')  # (windowed on the box: tools/profile_collect.py --window)
-for n in ('solve_stamps.txt', 'solve_ab_time.txt', 'overlap_probe.txt', 'general_path_parity.txt'):
+for n in ('solve_stamps.txt', 'solve_ab_time.txt', 'overlap_probe.txt', 'general_path_parity.txt', 'ubench_lds_neighbour.txt'):
     if os.path.exists(f'{F}/{n}'):
         shutil.copy(f'{F}/{n}', f'{P}/{tag}_{n}')
 if os.path.exists(f'{F}/bench_collective.json'):

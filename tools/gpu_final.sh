@@ -47,11 +47,13 @@ head -c 900 $F/pmc_general.json
 SMPLFIT_LIB=build_ab/libwstamp.so timeout 200 python tools/wave_stamps.py 4096 > $F/wave_stamps_4096.txt 2>&1 < /dev/null; head -12 $F/wave_stamps_4096.txt
 # round 6: the fused combine + solve kernel — phase stamps (debug build), event times against the two-kernel path, the
 # overlap probe (pair-Gram under the residual pass), the result gather (world-1 RCCL: overlapped / in line / none)
-{ for a in "4096 smpl" "16384 smpl" "4096 smplx"; do SMPLFIT_LIB=build_ab/libsstamp.so timeout 200 python tools/solve_stamps.py $a 2>&1 | grep -v amdgpu.ids; done; } > $F/solve_stamps.txt < /dev/null; head -9 $F/solve_stamps.txt
-{ timeout 300 python tools/solve_ab_time.py smpl; timeout 300 python tools/solve_ab_time.py smplx 2048 4096 8192; } 2>&1 | grep -v amdgpu.ids > $F/solve_ab_time.txt < /dev/null; cat $F/solve_ab_time.txt
-timeout 200 python tools/overlap_probe.py smpl 4096 2>&1 | grep -v amdgpu.ids > $F/overlap_probe.txt < /dev/null; cat $F/overlap_probe.txt
+{ for a in "4096 smpl" "16384 smpl" "4096 smplx"; do SMPLFIT_LIB=build_ab/libsstamp.so timeout 200 python tools/solve_stamps.py $a 2>&1 < /dev/null | grep -v amdgpu.ids; done; } > $F/solve_stamps.txt; head -9 $F/solve_stamps.txt
+{ timeout 300 python tools/solve_ab_time.py smpl < /dev/null; timeout 300 python tools/solve_ab_time.py smplx 2048 4096 8192 < /dev/null; } 2>&1 | grep -v amdgpu.ids > $F/solve_ab_time.txt; cat $F/solve_ab_time.txt
+timeout 200 python tools/overlap_probe.py smpl 4096 2>&1 < /dev/null | grep -v amdgpu.ids > $F/overlap_probe.txt; cat $F/overlap_probe.txt
 timeout 300 python bench.py --steps 50 --warmup 5 --collective-always --no-cpu-baseline > $F/bench_collective.json 2>/dev/null < /dev/null; python -c "
 import json
 d=[json.loads(l) for l in open('$F/bench_collective.json') if l.startswith('{')][0]; print('collective-always', d['value'], d['ms_per_step'], json.dumps(d['multi_gpu'])[:900])"
 # the general path's fixtures with the fp64 arbiter line, and the differentiable fit's rate
-timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -s -k "general_goldens" 2>&1 | grep "general\|passed\|failed" > $F/general_path_parity.txt < /dev/null; tail -4 $F/general_path_parity.txt
+timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -s -k "general_goldens" 2>&1 < /dev/null | grep "general\|passed\|failed" > $F/general_path_parity.txt; tail -4 $F/general_path_parity.txt
+# the neighbour-fault reproducer of round 6 (tools/ubench/lds_neighbour_r6.hip, built here: build_ab/)
+[ -x build_ab/lds_neighbour_r6 ] && timeout 300 build_ab/lds_neighbour_r6 > $F/ubench_lds_neighbour.txt 2>&1 < /dev/null; tail -3 $F/ubench_lds_neighbour.txt
