@@ -321,7 +321,7 @@ def test_edge_batches(model_root, golden, dev):
         m(pose_rotvecs=np.zeros((1, 72), np.float32))
 
 
-@pytest.mark.parametrize('name,B', [('smpl', 4096), ('smpl', 37), ('smpl', 1000), ('smplx', 2304), ('smpl1024', 16384)])
+@pytest.mark.parametrize('name,B', [('smpl', 4096), ('smpl', 37), ('smpl', 1000), ('smpl', 1001), ('smplx', 2304), ('smpl1024', 16384)])
 def test_solve_bm_matches_two_kernels(name, B, model_root, golden, dev, smplfit_env):
     """k_solve_bm (round 6: the normal-equation combine + the shape solve as one kernel, lane = instance) forms every
     sum in the order of k_gram_combine_bm + sf::solve_stage: its fits must equal the two-kernel path's bit for bit —
@@ -359,7 +359,7 @@ def test_solve_bm_matches_two_kernels(name, B, model_root, golden, dev, smplfit_
             assert np.array_equal(new[c][k], ref[c][k]), (c, k, float(np.abs(new[c][k] - ref[c][k]).max()))
 
 
-@pytest.mark.parametrize('name,B', [('smpl', 4096), ('smpl', 37), ('smplx', 2304), ('smpl1024', 16384)])
+@pytest.mark.parametrize('name,B', [('smpl', 4096), ('smpl', 37), ('smpl', 1001), ('smplx', 2304), ('smpl1024', 16384)])
 def test_prologue_bm_matches_joint_stage(name, B, model_root, golden, dev, smplfit_env):
     """k_prologue_bm (round 6: the shape prologue of the joint stage with lane = instance and a wave per joint, writing
     ws.jdT / ws.pextT / partial joint blocks) against the prologue inside k_joint_stage + the transpose launch: the FK
