@@ -38,6 +38,48 @@ def test_primitives(golden):
     assert np.abs(Ra[-4:] - np.eye(3)).max() == 0  # exactly antiparallel: zero rotvec -> identity
 
 
+def test_proj_so3_against_fp64_svd():
+    """sf::proj_so3 (round 6: Horn's closed form, Jacobi sweeps behind it) against the nearest rotation from numpy's fp64
+    SVD with the reference's reflection fix (pt/rotation.py:100-110) on sets where that rotation is unique: random,
+    badly scaled, nearly singular, reflected (det < 0 with separated singular values) and rank 2."""
+    lib = H.load()
+    rs = np.random.RandomState(5)
+
+    def with_sv(sv, reflect):
+        n = len(sv)
+        U, _ = np.linalg.qr(rs.randn(n, 3, 3))
+        V, _ = np.linalg.qr(rs.randn(n, 3, 3))
+        U[:, :, 2] *= np.sign(np.linalg.det(U))[:, None]
+        V[:, :, 2] *= np.sign(np.linalg.det(V))[:, None]
+        sv = np.array(sv, np.float64)
+        if reflect:
+            sv[:, 2] *= -1
+        return U @ (sv[:, :, None] * np.swapaxes(V, -1, -2))
+
+    n = 2000
+    sets = {
+        'random': rs.randn(n, 3, 3),
+        'scaled': rs.randn(n, 3, 3) * 10.0 ** rs.uniform(-4, 4, size=(n, 1, 1)),
+        'near_singular': with_sv(np.stack([rs.uniform(0.5, 2, n), rs.uniform(0.1, 0.4, n), rs.uniform(1e-5, 1e-3, n)], 1), False),
+        'reflected': with_sv(np.stack([rs.uniform(1, 2, n), rs.uniform(0.5, 0.9, n), rs.uniform(0.05, 0.4, n)], 1), True),
+        'rank2': with_sv(np.stack([rs.uniform(1, 2, n), rs.uniform(0.3, 0.9, n), np.zeros(n)], 1), False),
+    }
+    for name, A64 in sets.items():
+        A = np.ascontiguousarray(A64.astype(np.float32))
+        R = np.zeros_like(A)
+        lib.hostemu_proj_so3(H._p(A), H._p(R), len(A))
+        U, s, Vt = np.linalg.svd(A.astype(np.float64))
+        d = np.sign(np.linalg.det(U @ Vt))
+        U[:, :, 2] *= d[:, None]
+        ref = U @ Vt
+        # where the two smallest singular values (with the reflection's sign) nearly cancel, the answer is ill-defined
+        ok = (s[:, 1] + d * s[:, 2]) > 1e-3 * s[:, 0]
+        assert ok.mean() > 0.9, name
+        err = np.abs(R.astype(np.float64) - ref)[ok].max()
+        assert err < 2e-6, (name, err)  # (3e-8 observed on every set: the rounding of the fp32 outputs)
+        assert np.abs(np.linalg.det(R.astype(np.float64)) - 1).max() < 1e-5, name
+
+
 @pytest.mark.parametrize('name', ['smpl', 'smplx', 'smpl1024'])
 def test_forward(name, model_root, golden):
     g = golden(name)
