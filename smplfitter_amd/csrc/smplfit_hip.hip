@@ -108,6 +108,10 @@ struct ShareView {
 
 constexpr int kMaxChunks = 4;  // batch chunks of one fit call run on the caller's stream + 3 side streams
 
+// k_refine_bm: the wave that owns an adjustable part (parts are grouped by their top-most adjustable ancestor, refine_bm_groups)
+constexpr int kRefMaxAdj = 16;
+struct RefGroups { int8_t wave[kRefMaxAdj]; };
+
 struct smplfit_handle {
   sf::HostTables t;
   DevModel d{};
@@ -115,6 +119,8 @@ struct smplfit_handle {
   std::vector<ShareView> views;
   std::vector<void*> allocs;
   bool has_device = false;
+  int refine_group_max = 0;  // most adjustable parts one wave of k_refine_bm gets (groups under one top-most adjustable ancestor)
+  RefGroups refine_groups{};
   // registers per lane the split-bf16 GEMM kernels were built with (hipFuncGetAttributes at create).  They must own
   // the whole register file of a CU (256 x 8 waves, see k_posedirs_gemm_bf16x3 "exclusive CU"); if a toolchain ever
   // allocates fewer, the fp32-MFMA GEMM is used instead
@@ -288,6 +294,7 @@ constexpr int kPgWaves = 8, kPgPairs = SMPLFIT_PG_PAIRS;
 constexpr int pair_gram_units(int J, int npairs) { return 2 * J + (npairs + kPgPairs - 1) / kPgPairs; }
 constexpr int pair_gram_workgroups(int J, int npairs) { return (pair_gram_units(J, npairs) + kPgWaves - 1) / kPgWaves; }
 constexpr int kProWaves = 8;  // joints (= waves) per workgroup of k_prologue_bm
+constexpr int kRefWaves = 8;  // waves per workgroup of k_refine_bm (64 instances; the waves take joints)
 constexpr int prologue_splits(int J) { return (J + kProWaves - 1) / kProWaves; }
 constexpr int kAccExtrasHost = 16;  // (= kAccExtras of kernels_bm.inc: the extras of the scaled solve behind a cell record)
 
@@ -441,6 +448,7 @@ struct Tuning {
   int bm_slots = 4096;     // SMPLFIT_BM_SLOTS: resident waves a batch-major vertex pass is dealt for (share-count choice)
   int gen_flush = 0;       // SMPLFIT_GEN_FLUSH: vertices between two fp64 additions of the general accumulate kernel's fp32 sums (0: 2048; a scaled iteration: every blend pass)
   bool gen_mfma = true;    // SMPLFIT_GEN_MFMA=0: the general path's vertex block on the vector ALUs (k_gen_accum) instead of the matrix cores (A/B)
+  bool refine_bm = true;   // SMPLFIT_REFINE_BM=0: the refinement + epilogue as the wave-per-instance k_refine_epilogue behind a part-sum combine instead of k_refine_bm (A/B)
   bool prologue_bm = true; // SMPLFIT_PROLOGUE_BM=0: the shape prologue inside k_joint_stage + the joint-row transpose instead of k_prologue_bm (A/B)
   bool solve_bm = true;    // SMPLFIT_SOLVE_BM=0: normal-equation combine + wave-per-instance solve as two launches instead of k_solve_bm (A/B)
   int bm_lds_kb = 0;       // SMPLFIT_BM_LDS_KB: LDS request of the two batch-major vertex passes padded to this (54: three
@@ -474,6 +482,7 @@ Tuning read_tuning() {
   if (const char* e = env("SMPLFIT_GEN_FLUSH")) t.gen_flush = std::max(atoi(e), 0);
   if (const char* e = env("SMPLFIT_SOLVE_BM")) t.solve_bm = e[0] != '0';
   if (const char* e = env("SMPLFIT_PROLOGUE_BM")) t.prologue_bm = e[0] != '0';
+  if (const char* e = env("SMPLFIT_REFINE_BM")) t.refine_bm = e[0] != '0';
   if (const char* e = env("SMPLFIT_BM_LDS_KB")) t.bm_lds_kb = std::min(std::max(atoi(e), 0), 64);
   return t;
 }
@@ -628,7 +637,7 @@ void launch_accum_w_bm(const smplfit_handle* h, const Workspace& ws, int B, hipS
 // (bodyfitter.py:1505-1517) — only those parts' slots are visited, the other rows of ws.psum become zero.
 template <int S, int KW>
 void launch_lbs_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStream_t st, bool write_v = false,
-                   bool adj_only = false, bool weighted = false, bool write_all = false, int regress = -1) {
+                   bool adj_only = false, bool weighted = false, bool write_all = false, int regress = -1, bool combine = true) {
   const DevModel& d = h->d;
   const int Mp = (int)align_up((size_t)B, 128);
   const size_t lds = (size_t)tune().bm_lds_kb * 1024;
@@ -652,7 +661,7 @@ void launch_lbs_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStrea
       hipLaunchKernelGGL((k_lbs_partsum_bm<S, KW>), share_grid(sv, Mp), dim3(64 * kBW), lds, st, d, sv, ws, B, Mp);
     }
   }
-  launch_psum_combine(d, sv, ws, B, Mp, st);
+  if (combine) launch_psum_combine(d, sv, ws, B, Mp, st);  // (k_refine_bm adds the rows of the last pass itself)
 }
 
 // the forward-only variant of the batch-major LBS pass (posed vertices left in ws.vpT): input side of a fused
@@ -1136,6 +1145,48 @@ void launch_joint_stage_fit(const smplfit_handle* h, JointStageArgs ja, const Wo
   }
 }
 
+// K6' (k_refine_bm): the refinement + epilogue with lane = instance, reading the part-sum rows of the last LBS pass
+// itself.  Applies where k_prologue_bm ran (pro: ws.GT holds the rotations of the last joint stage, coarse cell tables)
+// on models whose joint arrays of 64 instances fit the LDS (at most 32 joints).
+// (groups of adjustable parts by their top-most adjustable ancestor: a wave of k_refine_bm takes a group — the groups are
+// dealt to the waves in turn — and keeps the part sums of its at most kRefParts parts in registers)
+int refine_bm_groups(const sf::HostTables& t, RefGroups* rg) {  // -> the most parts a wave gets
+  const int nadj = t.adj_level_start[t.adj_last_level + 1];
+  if (nadj > kRefMaxAdj) return 1 << 20;
+  std::vector<int> top(nadj), per_wave(kRefWaves, 0);
+  int ntop = 0, mx = 0;
+  for (int ai = 0; ai < nadj; ++ai) {
+    top[ai] = ai;
+    for (int p = t.adj_parts[ai]; p > 0;) {  // up to the root: the group of the nearest adjustable ancestor is the group of the top-most one
+      p = t.parents[p];
+      for (int a2 = 0; a2 < ai; ++a2)
+        if (t.adj_parts[a2] == p && top[ai] == ai) top[ai] = top[a2];
+    }
+    rg->wave[ai] = (int8_t)(top[ai] == ai ? (ntop++) % kRefWaves : rg->wave[top[ai]]);
+    mx = std::max(mx, ++per_wave[rg->wave[ai]]);
+  }
+  return mx;
+}
+bool refine_bm_applies(const smplfit_handle* h, bool pro) {
+  return pro && tune().refine_bm && h->d.J <= 32 && h->refine_group_max <= kRefParts &&
+         (size_t)refine_bm_lds_floats(h->d.J) * 4 <= 160 * 1024;
+}
+// sv: the table of the LBS pass whose rows hold the part sums (unused without final_adjust)
+void launch_refine_bm(const smplfit_handle* h, RefineArgs ra, const ShareView& sv, const Workspace& ws, int B, hipStream_t st) {
+  const DevModel& d = h->d;
+  const int Mp = (int)align_up((size_t)B, 128);
+  ra.B = B;
+  ra.b0 = 0;
+  const size_t lds = (size_t)refine_bm_lds_floats(d.J) * 4;
+  if (d.S == 11) {
+    if (lds > 64 * 1024) ensure_max_lds(reinterpret_cast<const void*>(&k_refine_bm<11>));
+    hipLaunchKernelGGL(k_refine_bm<11>, dim3((B + 63) / 64), dim3(64 * kRefWaves), lds, st, d, ra, sv, ws, ws.rjoints, Mp, h->refine_groups);
+  } else {
+    if (lds > 64 * 1024) ensure_max_lds(reinterpret_cast<const void*>(&k_refine_bm<10>));
+    hipLaunchKernelGGL(k_refine_bm<10>, dim3((B + 63) / 64), dim3(64 * kRefWaves), lds, st, d, ra, sv, ws, ws.rjoints, Mp, h->refine_groups);
+  }
+}
+
 int post_launch_check() {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(SMPLFIT_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
@@ -1358,6 +1409,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   }
   // (every solve of this call is k_solve_bm: the prologue runs as k_prologue_bm, which also writes ws.jdT)
   const bool pro = bm && !o.rotations_only && !eff_v && !o.scale_mode && !o.share_beta && prologue_bm_applies(h, B);
+  const bool rbm = refine_bm_applies(h, pro);  // the refinement as k_refine_bm (adds the last pass's part-sum rows itself)
   if (on(0)) launch_joint_stage_fit(h, ja, ws, B, st, pro);
   if (o.rotations_only) {
     if (on(0)) hipLaunchKernelGGL(k_copy, dim3(256), dim3(256), 0, st, ws.G, orient, (size_t)B * d.J * 9);
@@ -1400,7 +1452,8 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     if (last && !o.final_adjust) break;  // nothing consumes the re-evaluated mesh
     if (!pb) {
     } else if (bm) {
-#define SF_CALL_LBS(S_, KW_) launch_lbs_bm<S_, KW_>(h, ws, B, st, !joints, last && joints && !tune().lbs_all_last, vweighted)
+#define SF_CALL_LBS(S_, KW_) \
+  launch_lbs_bm<S_, KW_>(h, ws, B, st, !joints, last && joints && !tune().lbs_all_last, vweighted, false, -1, !(last && rbm))
       SF_DISPATCH_SKW(d, SF_CALL_LBS);
 #undef SF_CALL_LBS
     } else if (joints) {
@@ -1435,7 +1488,10 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     if (o.scale_out)
       hipLaunchKernelGGL(k_copy, dim3(16), dim3(256), 0, st, ws.scale, o.scale_out, (size_t)B);
   }
-  launch_refine(d, ra, ws, B, st);
+  if (rbm)  // (the table of the last LBS pass: every slot without target joints, else the adjustable / the used parts)
+    launch_refine_bm(h, ra, share_view(h, !joints ? sf::kShareLbsAll : tune().lbs_all_last ? sf::kShareLbsUsed : sf::kShareLbsAdj, B), ws, B, st);
+  else
+    launch_refine(d, ra, ws, B, st);
   return post_launch_check();
 }
 
@@ -2039,6 +2095,7 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
   }
   h->have_streams = true;
   h->has_device = true;
+  h->refine_group_max = refine_bm_groups(h->t, &h->refine_groups);
   *out = h;
   return SMPLFIT_OK;
 }
@@ -2666,7 +2723,9 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
         ra.kid = nullptr;
         ra.orient = ra.trans + (size_t)batch * 3;  // (a fit always writes the orientations and the relative rotations)
         ra.rel = ra.orient + (size_t)batch * d.J * 9;
-        launch_refine(d, ra, ws, batch, st);
+        // (what a default fit runs: k_refine_bm on the rows of the last LBS pass where that applies)
+        if (refine_bm_applies(h, bm && prologue_bm_applies(h, batch))) launch_refine_bm(h, ra, share_view(h, sf::kShareLbsAdj, batch), ws, batch, st);
+        else launch_refine(d, ra, ws, batch, st);
         return 0;
       }
       case SMPLFIT_KERNEL_GRAM_COMBINE:
@@ -2692,7 +2751,8 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
         return 0;
       case SMPLFIT_KERNEL_LBS_LAST:
         if (!bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "last LBS pass: batch-major path not active");
-#define SF_CALL_LBS(S_, KW_) launch_lbs_bm<S_, KW_>(h, ws, batch, st, false, true)
+#define SF_CALL_LBS(S_, KW_) \
+  launch_lbs_bm<S_, KW_>(h, ws, batch, st, false, true, false, false, -1, !refine_bm_applies(h, prologue_bm_applies(h, batch)))
         SF_DISPATCH_SKW(d, SF_CALL_LBS);
 #undef SF_CALL_LBS
         return 0;

@@ -409,6 +409,58 @@ def test_prologue_bm_matches_joint_stage(name, B, model_root, golden, dev, smplf
             assert dv < (8e-5 if name == 'smplx' else 4e-5), (c, 'vertices', dv)  # (thin-finger SMPL-X: ill-conditioned in the reference itself, util.pose_tol)
 
 
+@pytest.mark.parametrize('name,B', [('smpl', 4096), ('smpl', 1001), ('smpl', 37), ('smpl1024', 16384), ('smplx', 2304)])
+def test_refine_bm_matches_wave_kernel(name, B, model_root, golden, dev, smplfit_env):
+    """k_refine_bm (round 6: the dependent refinement + epilogue with lane = instance, the part-sum rows of the last LBS
+    pass added inside, the adjustable parts walked by dependency instead of by level) against k_psum_combine +
+    k_refine_epilogue: the same formulas on the same inputs.  Shape and translation pass through: bit for bit; without
+    the final adjustment the orientations are bit-identical too (the log map differs in the last bit).  With it the two
+    compilations of the stage round differently in the last bit of the cross-covariances, which the projection of the
+    smallest parts amplifies (ankles: up to 4.5e-5 in a rotation entry over 4096 noisy instances, median 1e-7): gated
+    like the other stage kernels — rotations 5e-4, the mesh 4e-5 m; run to run bit-identical.  Joints given / omitted,
+    joint weights, the kid unknown, an odd ragged batch.  (SMPL-X: 55 joints do not fit the kernel's LDS — both runs take
+    the wave kernel and must agree exactly; B = 37: the fine tables, likewise.)"""
+    from smplfitter_amd.pt import BodyFitter
+
+    g = golden(name)
+    m, f = get_model(model_root, name, g, dev)
+    fk = BodyFitter(m, enable_kid=True)
+    tv, tj = make_targets(m, B, 31, dev, noise=0.003)
+    jw = torch.rand(B, m.num_joints, device=dev) + 0.5
+    keys = ['pose_rotvecs', 'shape_betas', 'trans', 'orientations', 'relative_orientations']
+
+    def calls():
+        out = {}
+        out['fit'] = to_np(f.fit(tv, tj, num_iter=3, beta_regularizer=1.0, requested_keys=keys))
+        out['fit_nofa'] = to_np(f.fit(tv, tj, num_iter=2, beta_regularizer=1.0, final_adjust_rots=False, requested_keys=keys))
+        if name != 'smpl1024':
+            out['fit_nojoints'] = to_np(f.fit(tv, None, num_iter=2, beta_regularizer=0.0, requested_keys=keys))
+        out['fit_kid'] = to_np(fk.fit(tv, tj, num_iter=2, beta_regularizer=1.0, requested_keys=keys + ['kid_factor']))
+        out['fit_jw'] = to_np(f.fit(tv, tj, joint_weights=jw, num_iter=2, beta_regularizer=1.0, requested_keys=keys[:3]))
+        return out
+
+    smplfit_env('SMPLFIT_REFINE_BM', '0')
+    ref = calls()
+    smplfit_env('SMPLFIT_REFINE_BM', '1')
+    new = calls()
+    again = calls()
+    same_kernel = name == 'smplx' or B <= 768
+    for c in ref:
+        for k in ref[c]:
+            assert np.isfinite(new[c][k]).all(), (c, k)
+            assert np.array_equal(new[c][k], again[c][k]), (c, k)
+            d = float(np.abs(new[c][k] - ref[c][k]).max())
+            if same_kernel or k in ('shape_betas', 'trans', 'kid_factor') or (c == 'fit_nofa' and k == 'orientations'):
+                assert d == 0, (c, k, d)
+            else:
+                assert d < (2e-6 if c == 'fit_nofa' else 5e-4), (c, k, d)
+        if not same_kernel and c != 'fit_kid':
+            va = m(t(new[c]['pose_rotvecs'], dev), t(new[c]['shape_betas'], dev), t(new[c]['trans'], dev))['vertices']
+            vb = m(t(ref[c]['pose_rotvecs'], dev), t(ref[c]['shape_betas'], dev), t(ref[c]['trans'], dev))['vertices']
+            dv = float((va - vb).norm(dim=-1).max().item())
+            assert dv < 4e-5, (c, 'vertices', dv)
+
+
 def test_stage_half(model_root, golden, dev, smplfit_env):
     """Two instances per wave in the per-instance stages (J <= 32, batches from SMPLFIT_STAGE_HALF_B = 2048 up by
     default): forced on at every batch size it must reproduce the reference's fixtures and agree with the
