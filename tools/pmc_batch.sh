@@ -19,7 +19,7 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
     first = next(i for i, r in enumerate(rows) if 'k_layout_targets' in r['Kernel_Name'])   # the fits start here
     rows = [r for r in rows[first:] if re.search(r'\bk_[a-z_0-9]+', r['Kernel_Name'])]
-    fits = sum('k_refine_epilogue' in r['Kernel_Name'] for r in rows) / ch
+    fits = sum(('k_refine_epilogue' in r['Kernel_Name'] or 'k_refine_bm' in r['Kernel_Name']) for r in rows) / ch
     tot[c] = sum(float(r['Counter_Value']) for r in rows) * 1024 / fits / B
 print(f'B {B} chunks {ch}: HBM bytes per fit {2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]:,.0f} '
       f'(reads {2 * tot["FETCH_SIZE"]:,.0f}, writes {tot["WRITE_SIZE"]:,.0f})')

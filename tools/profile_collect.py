@@ -19,6 +19,9 @@ def short(n):
     return m.group(1) if m else n.split('(')[0][:48]
 
 
+REFINE = ('k_refine_epilogue', 'k_refine_bm')  # the last kernel of a fit (round 6: the lane = instance form for models of <= 32 joints)
+
+
 def trace_rows(d):
     rows = []
     for f in glob.glob(f'{d}/**/*kernel_trace.csv', recursive=True):
@@ -35,13 +38,13 @@ def stats_csv(rows, path, head, chunks, warm=3):
     # steady state = the timed fits of the bench command: every fit ends with one k_refine_epilogue per chunk; the
     # window opens when the last warm-up fit has ended and closes with the last timed fit (bench.py's roofline leg —
     # repeated single-kernel launches — comes after it and is left out)
-    ends = sorted(e for s, e, n in rows if short(n) == 'k_refine_epilogue')
+    ends = sorted(e for s, e, n in rows if short(n) in REFINE)
     # (bench.py's roofline leg launches k_refine_epilogue too — timing hook 10, round 5: only the refinements of the
     # warm-up and timed fits count)
     ends = ends[:(warm + STEPS) * chunks]
     t_lo, t_hi = ends[warm * chunks - 1], ends[-1]
     nfit = (len(ends) - warm * chunks) // chunks
-    head += f'; statistics over the {nfit} timed fits (window between the {warm}rd and the last k_refine_epilogue)'
+    head += f'; statistics over the {nfit} timed fits (window between the end of the {warm}rd and of the last refinement kernel)'
     rows = [r for r in rows if r[0] >= t_lo and r[1] <= t_hi]
     per = collections.defaultdict(list)
     for s, e, n in rows:
@@ -104,12 +107,12 @@ for k in sorted(set(fetch) | set(write)):
 rows = trace_rows(f'{src}/trace1')
 # only the fits themselves: bench.py's roofline leg (smplfit_time_kernel_f32: repeated single-kernel launches) and
 # its round-trip forward come after the last fit's epilogue
-fit_ends = sorted(e for s, e, n in rows if short(n) == 'k_refine_epilogue')[:3 + STEPS]  # (not the timing hook's launches)
+fit_ends = sorted(e for s, e, n in rows if short(n) in REFINE)[:3 + STEPS]  # (not the timing hook's launches)
 last_fit_end = fit_ends[-1] if fit_ends else None
 if last_fit_end is not None:
     rows = [r for r in rows if r[0] <= last_fit_end]
 cnt = collections.Counter(short(n) for s, e, n in rows)
-fits = max(1, cnt.get('k_refine_epilogue', 1))
+fits = max(1, sum(cnt.get(k, 0) for k in REFINE) or 1)
 per_fit = 0
 for k, v in kern.items():
     v['launches_per_fit'] = round(cnt.get(k, 0) / fits, 2)
