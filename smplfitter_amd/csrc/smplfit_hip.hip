@@ -448,6 +448,7 @@ struct Tuning {
   int bm_slots = 4096;     // SMPLFIT_BM_SLOTS: resident waves a batch-major vertex pass is dealt for (share-count choice)
   int gen_flush = 0;       // SMPLFIT_GEN_FLUSH: vertices between two fp64 additions of the general accumulate kernel's fp32 sums (0: 2048; a scaled iteration: every blend pass)
   bool gen_mfma = true;    // SMPLFIT_GEN_MFMA=0: the general path's vertex block on the vector ALUs (k_gen_accum) instead of the matrix cores (A/B)
+  bool rot_bm = true;      // SMPLFIT_ROT_BM=0: the part rotations as the wave-per-instance k_joint_stage behind a part-sum combine instead of k_rotations_bm (A/B)
   bool refine_bm = true;   // SMPLFIT_REFINE_BM=0: the refinement + epilogue as the wave-per-instance k_refine_epilogue behind a part-sum combine instead of k_refine_bm (A/B)
   bool prologue_bm = true; // SMPLFIT_PROLOGUE_BM=0: the shape prologue inside k_joint_stage + the joint-row transpose instead of k_prologue_bm (A/B)
   bool solve_bm = true;    // SMPLFIT_SOLVE_BM=0: normal-equation combine + wave-per-instance solve as two launches instead of k_solve_bm (A/B)
@@ -483,6 +484,7 @@ Tuning read_tuning() {
   if (const char* e = env("SMPLFIT_SOLVE_BM")) t.solve_bm = e[0] != '0';
   if (const char* e = env("SMPLFIT_PROLOGUE_BM")) t.prologue_bm = e[0] != '0';
   if (const char* e = env("SMPLFIT_REFINE_BM")) t.refine_bm = e[0] != '0';
+  if (const char* e = env("SMPLFIT_ROT_BM")) t.rot_bm = e[0] != '0';
   if (const char* e = env("SMPLFIT_BM_LDS_KB")) t.bm_lds_kb = std::min(std::max(atoi(e), 0), 64);
   return t;
 }
@@ -550,19 +552,20 @@ void launch_psum_combine(const DevModel& d, const ShareView& sv, const Workspace
 }
 
 // part sums of the centred targets against the template + their combine (the first rotation estimate)
-void launch_template_partsum_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStream_t st, bool weighted = false) {
+void launch_template_partsum_bm(const smplfit_handle* h, const Workspace& ws, int B, hipStream_t st, bool weighted = false,
+                                bool combine = true) {
   const DevModel& d = h->d;
   const int Mp = (int)align_up((size_t)B, 128);
   const ShareView sv = share_view(h, sf::kShareLbsUsed, B);
   if (weighted) hipLaunchKernelGGL(k_template_partsum_bm<true>, share_grid(sv, Mp), dim3(64 * kBW), 0, st, d, sv, ws, B, Mp);
   else hipLaunchKernelGGL(k_template_partsum_bm<false>, share_grid(sv, Mp), dim3(64 * kBW), 0, st, d, sv, ws, B, Mp);
-  launch_psum_combine(d, sv, ws, B, Mp, st);
+  if (combine) launch_psum_combine(d, sv, ws, B, Mp, st);  // (k_rotations_bm adds the rows itself)
 }
 
 // One-pass target layout of the batch-major path (k_layout_targets, k_mean_finish, k_template_partsum_bm):
 // ws.tT, ws.mean, ws.tjc and the template part sums ws.psum.  ws.resP serves as the slab-sum scratch.
 void launch_layout_bm(const smplfit_handle* h, const float* tv, const float* tj, const Workspace& ws, int B, hipStream_t st,
-                      const float* vw = nullptr, bool template_sums = true) {
+                      const float* vw = nullptr, bool template_sums = true, bool combine = true) {
   const DevModel& d = h->d;
   if (vw)  // vertex weights: their stream first (the template part sums below read it)
     hipLaunchKernelGGL(k_layout_weights, dim3((d.V + 63) / 64 + 1, (int)align_up((size_t)B, 128) / 64), dim3(256), 0, st, d, vw,
@@ -572,7 +575,7 @@ void launch_layout_bm(const smplfit_handle* h, const float* tv, const float* tj,
                      ws.resP, B, Mp);
   hipLaunchKernelGGL(k_mean_finish, dim3(Mp / 64), dim3(64 * kMeanWaves), 0, st, d, tj, ws.resP, ws, B, Mp, nslab);
   // (a warm-started fit takes its first part sums against the posed initial model instead)
-  if (template_sums) launch_template_partsum_bm(h, ws, B, st, vw != nullptr);
+  if (template_sums) launch_template_partsum_bm(h, ws, B, st, vw != nullptr, combine);
 }
 
 // K3' + K3g + K3c of the batch-major path for 10 betas (S = 10) and 10 betas + the kid unknown (S = 11)
@@ -1133,12 +1136,29 @@ void launch_prologue_bm(const smplfit_handle* h, const JointStageArgs& ja, const
 }
 // the joint stage of a fit on the batch-major path: rotations by k_joint_stage, the prologue by k_prologue_bm (pro), or
 // both by k_joint_stage
-void launch_joint_stage_fit(const smplfit_handle* h, JointStageArgs ja, const Workspace& ws, int B, hipStream_t st, bool pro) {
+// K1r (k_rotations_bm): the part rotations with lane = instance, adding the part-sum rows of the pass in front of it
+// itself.  rot_kind: the cell table of that pass (its rows), or -1: k_joint_stage fits the rotations.  gprev_mode: where
+// the previous rotations come from (0 none, 1 ws.GT, 2 the instance-major ja.Gprev).
+void launch_rotations_bm(const smplfit_handle* h, const JointStageArgs& ja, int rot_kind, int gprev_mode, const Workspace& ws, int B,
+                         hipStream_t st) {
+  const DevModel& d = h->d;
+  const int Mp = (int)align_up((size_t)B, 128);
+  RotArgs ra{ja.tj, ja.rj, ja.jw, ja.Gprev, ja.rj_shared, gprev_mode, B};
+  const size_t lds = (size_t)rot_bm_lds_floats(d.J) * 4;
+  if (lds > 64 * 1024) ensure_max_lds(reinterpret_cast<const void*>(&k_rotations_bm));
+  hipLaunchKernelGGL(k_rotations_bm, dim3((B + 63) / 64), dim3(64 * kRefWaves), lds, st, d, ra, share_view(h, rot_kind, B), ws, Mp);
+}
+void launch_joint_stage_fit(const smplfit_handle* h, JointStageArgs ja, const Workspace& ws, int B, hipStream_t st, bool pro,
+                            int rot_kind = -1, int gprev_mode = 0) {
   if (pro && ja.do_prologue) {
-    ja.do_prologue = 0;
-    ja.gt_pitch = (int)align_up((size_t)B, 128);
-    launch_joint_stage(h->d, ja, ws, B, st);
-    ja.do_prologue = 1;
+    if (rot_kind >= 0) {
+      launch_rotations_bm(h, ja, rot_kind, gprev_mode, ws, B, st);
+    } else {
+      ja.do_prologue = 0;
+      ja.gt_pitch = (int)align_up((size_t)B, 128);
+      launch_joint_stage(h->d, ja, ws, B, st);
+      ja.do_prologue = 1;
+    }
     launch_prologue_bm(h, ja, ws, B, st);
   } else {
     launch_joint_stage(h->d, ja, ws, B, st);
@@ -1170,6 +1190,11 @@ int refine_bm_groups(const sf::HostTables& t, RefGroups* rg) {  // -> the most p
 bool refine_bm_applies(const smplfit_handle* h, bool pro) {
   return pro && tune().refine_bm && h->d.J <= 32 && h->refine_group_max <= kRefParts &&
          (size_t)refine_bm_lds_floats(h->d.J) * 4 <= 160 * 1024;
+}
+// (k_rotations_bm goes with k_refine_bm: once it runs, nothing writes the instance-major ws.G / ws.psum any more)
+bool rot_bm_applies(const smplfit_handle* h, bool pro) {
+  return refine_bm_applies(h, pro) && tune().rot_bm && h->d.J <= kRotJoints * kRefWaves &&
+         (size_t)rot_bm_lds_floats(h->d.J) * 4 <= 160 * 1024;
 }
 // sv: the table of the LBS pass whose rows hold the part sums (unused without final_adjust)
 void launch_refine_bm(const smplfit_handle* h, RefineArgs ra, const ShareView& sv, const Workspace& ws, int B, hipStream_t st) {
@@ -1338,6 +1363,10 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   const bool bm_base = bm_applies(h) && !o.rotations_only && (!o.scale_mode || (tune().bm_scale && d.S == 10 && d.KW == 4));
   const bool bm = bm_base && (!vw || (tune().bm_weighted && (!eff_v || (d.S == 10 && d.KW == 4))));
   if (o.source && !bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "fused conversion: the batch-major path does not apply");
+  // (every solve of this call is k_solve_bm: the prologue runs as k_prologue_bm, which also writes ws.jdT)
+  const bool pro = bm && !o.rotations_only && !eff_v && !o.scale_mode && !o.share_beta && prologue_bm_applies(h, B);
+  const bool rbm = refine_bm_applies(h, pro);  // the refinement as k_refine_bm (adds the last pass's part-sum rows itself)
+  const bool rotbm = rot_bm_applies(h, pro);   // the part rotations as k_rotations_bm (adds the part-sum rows itself)
   // (a warm-started fit evaluates its first part sums against the posed initial model: on the batch-major path with
   // the LBS pass of the iterations — until round 4 with the wave-per-instance kernel over a second, sorted copy)
   if (on(0) && !bm) launch_center_sort(d, tv, tj, vw, ws, B, st);
@@ -1345,7 +1374,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   } else if (bm && o.source) {
     if (int rc = launch_convert_source(*o.source, d, ws, B, st)) return rc;
   } else if (bm) {
-    launch_layout_bm(h, tv, tj, ws, B, st, vw, !(o.init_pose || o.init_betas));
+    launch_layout_bm(h, tv, tj, ws, B, st, vw, !(o.init_pose || o.init_betas), !rotbm);
   }
   const float* tj_rot = ws.tjc;
   if (!joints) {  // regressed target joints from the centred vertices (bodyfitter.py:1342-1344)
@@ -1386,7 +1415,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
       launch_forward_joint(d, fa, ws, B, st);
       if (int rc = launch_gemm(d, ws, B, st, true)) return rc;
       launch_jd_transpose(d, ws, B, st);
-#define SF_CALL_LBS(S_, KW_) launch_lbs_bm<S_, KW_>(h, ws, B, st, !joints, false, vweighted)
+#define SF_CALL_LBS(S_, KW_) launch_lbs_bm<S_, KW_>(h, ws, B, st, !joints, false, vweighted, false, -1, !rotbm)
       SF_DISPATCH_SKW(d, SF_CALL_LBS);
 #undef SF_CALL_LBS
     } else if (on(0)) {
@@ -1407,10 +1436,11 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     ja.rj = ws.rjreg;
     ja.rj_shared = 1;
   }
-  // (every solve of this call is k_solve_bm: the prologue runs as k_prologue_bm, which also writes ws.jdT)
-  const bool pro = bm && !o.rotations_only && !eff_v && !o.scale_mode && !o.share_beta && prologue_bm_applies(h, B);
-  const bool rbm = refine_bm_applies(h, pro);  // the refinement as k_refine_bm (adds the last pass's part-sum rows itself)
-  if (on(0)) launch_joint_stage_fit(h, ja, ws, B, st, pro);
+  // (first rotations: the rows of the template pass — or of the warm start's LBS pass —; previous rotations: the
+  // instance-major ws.G of the warm start's forward stage, if any)
+  if (on(0))
+    launch_joint_stage_fit(h, ja, ws, B, st, pro, !rotbm ? -1 : (warm && !joints) ? sf::kShareLbsAll : sf::kShareLbsUsed,
+                           ja.Gprev ? 2 : 0);
   if (o.rotations_only) {
     if (on(0)) hipLaunchKernelGGL(k_copy, dim3(256), dim3(256), 0, st, ws.G, orient, (size_t)B * d.J * 9);
     return post_launch_check();
@@ -1453,7 +1483,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     if (!pb) {
     } else if (bm) {
 #define SF_CALL_LBS(S_, KW_) \
-  launch_lbs_bm<S_, KW_>(h, ws, B, st, !joints, last && joints && !tune().lbs_all_last, vweighted, false, -1, !(last && rbm))
+  launch_lbs_bm<S_, KW_>(h, ws, B, st, !joints, last && joints && !tune().lbs_all_last, vweighted, false, -1, !(last ? rbm : rotbm))
       SF_DISPATCH_SKW(d, SF_CALL_LBS);
 #undef SF_CALL_LBS
     } else if (joints) {
@@ -1466,7 +1496,7 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
     ja.rj = joints ? ws.rjoints : ws.rjreg;
     ja.rj_shared = 0;
     ja.Gprev = ws.G;
-    if (pb) launch_joint_stage_fit(h, ja, ws, B, st, pro);
+    if (pb) launch_joint_stage_fit(h, ja, ws, B, st, pro, !rotbm ? -1 : !joints ? sf::kShareLbsAll : sf::kShareLbsUsed, 1);
   }
   if (!on(1 + 2 * o.num_iter)) return post_launch_check();
   RefineArgs ra{};
@@ -2686,7 +2716,8 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
         return 0;
       case SMPLFIT_KERNEL_LBS_PARTSUM: {
         if (bm) {
-#define SF_CALL_LBS(S_, KW_) launch_lbs_bm<S_, KW_>(h, ws, batch, st)
+#define SF_CALL_LBS(S_, KW_) \
+  launch_lbs_bm<S_, KW_>(h, ws, batch, st, false, false, false, false, -1, !rot_bm_applies(h, prologue_bm_applies(h, batch)))
           SF_DISPATCH_SKW(d, SF_CALL_LBS);
 #undef SF_CALL_LBS
           return 0;
@@ -2707,7 +2738,10 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
         ja.joint_block_weighted = 0;
         ja.vertex_sa_closed_form = d.general ? 0 : 1;
         // (what a default fit runs: the rotations + k_prologue_bm where that applies)
-        launch_joint_stage_fit(h, ja, ws, batch, st, bm && prologue_bm_applies(h, batch));
+        {
+          const bool pro_h = bm && prologue_bm_applies(h, batch);
+          launch_joint_stage_fit(h, ja, ws, batch, st, pro_h, rot_bm_applies(h, pro_h) ? sf::kShareLbsUsed : -1, 1);
+        }
         return 0;
       }
       case SMPLFIT_KERNEL_REFINE: {  // (outputs into the workspace: ws.tvs is unused between fits)
@@ -2735,6 +2769,7 @@ int smplfit_time_kernel_f32(const smplfit_handle* h, int kernel_id, int batch, i
         return 0;
       case SMPLFIT_KERNEL_PSUM_COMBINE:
         if (!bm) return fail(SMPLFIT_ERR_UNSUPPORTED, "part-sum combine: batch-major path not active");
+        if (rot_bm_applies(h, prologue_bm_applies(h, batch))) return fail(SMPLFIT_ERR_UNSUPPORTED, "part-sum combine: k_rotations_bm / k_refine_bm add the rows themselves");
         launch_psum_combine(d, share_view(h, sf::kShareLbsUsed, batch), ws, batch, Mp, st);
         return 0;
       case SMPLFIT_KERNEL_JD_TRANSPOSE:

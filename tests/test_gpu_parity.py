@@ -409,6 +409,58 @@ def test_prologue_bm_matches_joint_stage(name, B, model_root, golden, dev, smplf
             assert dv < (8e-5 if name == 'smplx' else 4e-5), (c, 'vertices', dv)  # (thin-finger SMPL-X: ill-conditioned in the reference itself, util.pose_tol)
 
 
+@pytest.mark.parametrize('name,B', [('smpl', 4096), ('smpl', 1001), ('smpl1024', 16384), ('smplx', 2304)])
+def test_rotations_bm_matches_joint_stage(name, B, model_root, golden, dev, smplfit_env):
+    """k_rotations_bm (round 6: the part rotations with lane = instance, a wave per joint, the part-sum rows of the pass in
+    front of it added inside) against k_psum_combine + the rotations of k_joint_stage: the formulas of sf::joint_stage on
+    the same inputs; the two compilations round differently in the last bit and every later stage sees it, so the fits
+    agree like those of the other stage kernels — rotations 5e-4, shape 6e-5, translation 3e-6, the mesh 4e-5 m — and are
+    bit-identical run to run.  Joints given / omitted, joint weights (the Kabsch of the multi-joint parts), the kid
+    unknown, one iteration, a warm start (previous rotations from the instance-major buffer), an odd ragged batch.
+    (SMPL-X: 55 joints — both runs take the wave kernel and must agree exactly.)"""
+    from smplfitter_amd.pt import BodyFitter
+
+    g = golden(name)
+    m, f = get_model(model_root, name, g, dev)
+    fk = BodyFitter(m, enable_kid=True)
+    tv, tj = make_targets(m, B, 37, dev, noise=0.003)
+    jw = torch.rand(B, m.num_joints, device=dev) + 0.5
+    keys = ['pose_rotvecs', 'shape_betas', 'trans']
+
+    def calls():
+        out = {}
+        out['fit'] = to_np(f.fit(tv, tj, num_iter=3, beta_regularizer=1.0, requested_keys=keys))
+        out['fit_it1'] = to_np(f.fit(tv, tj, num_iter=1, beta_regularizer=1.0, requested_keys=keys))
+        if name != 'smpl1024':
+            out['fit_nojoints'] = to_np(f.fit(tv, None, num_iter=2, beta_regularizer=0.0, requested_keys=keys))
+        out['fit_kid'] = to_np(fk.fit(tv, tj, num_iter=2, beta_regularizer=1.0, requested_keys=keys))
+        out['fit_jw'] = to_np(f.fit(tv, tj, joint_weights=jw, num_iter=2, beta_regularizer=1.0, requested_keys=keys))
+        pose = torch.from_numpy(out['fit']['pose_rotvecs']).to(dev)
+        betas = torch.from_numpy(out['fit']['shape_betas']).to(dev)
+        out['warm'] = to_np(f.fit(tv, tj, num_iter=1, beta_regularizer=0.5, initial_pose_rotvecs=pose,
+                                  initial_shape_betas=betas, requested_keys=keys))
+        return out
+
+    smplfit_env('SMPLFIT_ROT_BM', '0')
+    ref = calls()
+    smplfit_env('SMPLFIT_ROT_BM', '1')
+    new = calls()
+    again = calls()
+    same_kernel = name == 'smplx'
+    tol = dict(pose_rotvecs=5e-4, shape_betas=6e-5, trans=3e-6)
+    for c in ref:
+        for k in ref[c]:
+            assert np.isfinite(new[c][k]).all(), (c, k)
+            assert np.array_equal(new[c][k], again[c][k]), (c, k)
+            d = float(np.abs(new[c][k] - ref[c][k]).max())
+            assert (d == 0) if same_kernel else (d < tol.get(k, 5e-4)), (c, k, d)
+        if not same_kernel and c != 'fit_kid':
+            va = m(t(new[c]['pose_rotvecs'], dev), t(new[c]['shape_betas'], dev), t(new[c]['trans'], dev))['vertices']
+            vb = m(t(ref[c]['pose_rotvecs'], dev), t(ref[c]['shape_betas'], dev), t(ref[c]['trans'], dev))['vertices']
+            dv = float((va - vb).norm(dim=-1).max().item())
+            assert dv < 4e-5, (c, 'vertices', dv)
+
+
 @pytest.mark.parametrize('name,B', [('smpl', 4096), ('smpl', 1001), ('smpl', 37), ('smpl1024', 16384), ('smplx', 2304)])
 def test_refine_bm_matches_wave_kernel(name, B, model_root, golden, dev, smplfit_env):
     """k_refine_bm (round 6: the dependent refinement + epilogue with lane = instance, the part-sum rows of the last LBS
@@ -439,6 +491,7 @@ def test_refine_bm_matches_wave_kernel(name, B, model_root, golden, dev, smplfit
         out['fit_jw'] = to_np(f.fit(tv, tj, joint_weights=jw, num_iter=2, beta_regularizer=1.0, requested_keys=keys[:3]))
         return out
 
+    smplfit_env('SMPLFIT_ROT_BM', '0')  # (k_rotations_bm goes with k_refine_bm: off in both runs, so that only the refinement differs)
     smplfit_env('SMPLFIT_REFINE_BM', '0')
     ref = calls()
     smplfit_env('SMPLFIT_REFINE_BM', '1')
