@@ -121,6 +121,8 @@ struct smplfit_handle {
   bool has_device = false;
   int refine_group_max = 0;  // most adjustable parts one wave of k_refine_bm gets (groups under one top-most adjustable ancestor)
   RefGroups refine_groups{};
+  int8_t rot_slots[64];      // k_rotations_bm: a joint's slot among the joints a toe copies, or -1
+  int rot_nslots = 0, rot_toes_per_wave = 0;
   // registers per lane the split-bf16 GEMM kernels were built with (hipFuncGetAttributes at create).  They must own
   // the whole register file of a CU (256 x 8 waves, see k_posedirs_gemm_bf16x3 "exclusive CU"); if a toolchain ever
   // allocates fewer, the fp32-MFMA GEMM is used instead
@@ -1143,10 +1145,16 @@ void launch_rotations_bm(const smplfit_handle* h, const JointStageArgs& ja, int 
                          hipStream_t st) {
   const DevModel& d = h->d;
   const int Mp = (int)align_up((size_t)B, 128);
-  RotArgs ra{ja.tj, ja.rj, ja.jw, ja.Gprev, ja.rj_shared, gprev_mode, B};
+  RotArgs ra{ja.tj, ja.rj, ja.jw, ja.Gprev, ja.rj_shared, gprev_mode, B, {}};
+  std::memcpy(ra.slot, h->rot_slots, sizeof(ra.slot));
   const size_t lds = (size_t)rot_bm_lds_floats(d.J) * 4;
-  if (lds > 64 * 1024) ensure_max_lds(reinterpret_cast<const void*>(&k_rotations_bm));
-  hipLaunchKernelGGL(k_rotations_bm, dim3((B + 63) / 64), dim3(64 * kRefWaves), lds, st, d, ra, share_view(h, rot_kind, B), ws, Mp);
+  if (d.J <= kRotJoints * kRefWaves) {
+    if (lds > 64 * 1024) ensure_max_lds(reinterpret_cast<const void*>(&k_rotations_bm));
+    hipLaunchKernelGGL(k_rotations_bm, dim3((B + 63) / 64), dim3(64 * kRefWaves), lds, st, d, ra, share_view(h, rot_kind, B), ws, Mp);
+  } else {
+    if (lds > 64 * 1024) ensure_max_lds(reinterpret_cast<const void*>(&k_rotations_bm_rounds));
+    hipLaunchKernelGGL(k_rotations_bm_rounds, dim3((B + 63) / 64), dim3(64 * kRefWaves), lds, st, d, ra, share_view(h, rot_kind, B), ws, Mp);
+  }
 }
 void launch_joint_stage_fit(const smplfit_handle* h, JointStageArgs ja, const Workspace& ws, int B, hipStream_t st, bool pro,
                             int rot_kind = -1, int gprev_mode = 0) {
@@ -1191,9 +1199,10 @@ bool refine_bm_applies(const smplfit_handle* h, bool pro) {
   return pro && tune().refine_bm && h->d.J <= 32 && h->refine_group_max <= kRefParts &&
          (size_t)refine_bm_lds_floats(h->d.J) * 4 <= 160 * 1024;
 }
-// (k_rotations_bm goes with k_refine_bm: once it runs, nothing writes the instance-major ws.G / ws.psum any more)
+// (once k_rotations_bm runs nothing writes the instance-major ws.G any more: a model whose refinement stays on
+// k_refine_epilogue — more than 32 joints — gets it from k_gt_to_g in front of that kernel)
 bool rot_bm_applies(const smplfit_handle* h, bool pro) {
-  return refine_bm_applies(h, pro) && tune().rot_bm && h->d.J <= kRotJoints * kRefWaves &&
+  return pro && tune().rot_bm && h->d.J <= kRotMaxJ && h->rot_nslots <= kRotSlots && h->rot_toes_per_wave <= 2 &&
          (size_t)rot_bm_lds_floats(h->d.J) * 4 <= 160 * 1024;
 }
 // sv: the table of the LBS pass whose rows hold the part sums (unused without final_adjust)
@@ -1520,8 +1529,11 @@ int run_fit(const smplfit_handle* h, const float* tv, const float* tj, const flo
   }
   if (rbm)  // (the table of the last LBS pass: every slot without target joints, else the adjustable / the used parts)
     launch_refine_bm(h, ra, share_view(h, !joints ? sf::kShareLbsAll : tune().lbs_all_last ? sf::kShareLbsUsed : sf::kShareLbsAdj, B), ws, B, st);
-  else
+  else {
+    if (rotbm)  // (k_rotations_bm left the rotations instance-innermost only)
+      hipLaunchKernelGGL(k_gt_to_g, dim3((B + 63) / 64, (d.J + 15) / 16), dim3(256), 0, st, ws, d.J, B, (int)align_up((size_t)B, 128));
     launch_refine(d, ra, ws, B, st);
+  }
   return post_launch_check();
 }
 
@@ -2126,6 +2138,16 @@ int smplfit_create(const smplfit_model_desc* desc, int flags, smplfit_handle** o
   h->have_streams = true;
   h->has_device = true;
   h->refine_group_max = refine_bm_groups(h->t, &h->refine_groups);
+  {
+    std::fill(h->rot_slots, h->rot_slots + 64, (int8_t)-1);
+    for (int j = 0; j < (int)h->t.toe_src.size() && j < 64; ++j) {
+      const int src = h->t.toe_src[j];
+      if (src >= 0 && src < 64 && h->rot_slots[src] < 0) h->rot_slots[src] = (int8_t)h->rot_nslots++;
+    }
+    int per_wave[kRefWaves] = {};  // toes of one wave of k_rotations_bm (joint j belongs to wave j % kRefWaves)
+    for (int j = 0; j < (int)h->t.toe_src.size(); ++j)
+      if (h->t.toe_src[j] >= 0) h->rot_toes_per_wave = std::max(h->rot_toes_per_wave, ++per_wave[j % kRefWaves]);
+  }
   *out = h;
   return SMPLFIT_OK;
 }

@@ -416,8 +416,9 @@ def test_rotations_bm_matches_joint_stage(name, B, model_root, golden, dev, smpl
     the same inputs; the two compilations round differently in the last bit and every later stage sees it, so the fits
     agree like those of the other stage kernels — rotations 5e-4, shape 6e-5, translation 3e-6, the mesh 4e-5 m — and are
     bit-identical run to run.  Joints given / omitted, joint weights (the Kabsch of the multi-joint parts), the kid
-    unknown, one iteration, a warm start (previous rotations from the instance-major buffer), an odd ragged batch.
-    (SMPL-X: 55 joints — both runs take the wave kernel and must agree exactly.)"""
+    unknown, one iteration, a warm start (previous rotations from the instance-major buffer), an odd ragged batch; the
+    SMPL-X-shaped model (55 joints: two rounds of joints per wave; its refinement stays on the wave kernel, which gets
+    the rotations through k_gt_to_g)."""
     from smplfitter_amd.pt import BodyFitter
 
     g = golden(name)
@@ -446,19 +447,20 @@ def test_rotations_bm_matches_joint_stage(name, B, model_root, golden, dev, smpl
     smplfit_env('SMPLFIT_ROT_BM', '1')
     new = calls()
     again = calls()
-    same_kernel = name == 'smplx'
-    tol = dict(pose_rotvecs=5e-4, shape_betas=6e-5, trans=3e-6)
+    # (the thin-finger SMPL-X fixture is ill-conditioned in the reference itself, util.pose_tol: its gates as in
+    # test_prologue_bm_matches_joint_stage)
+    tol = dict(pose_rotvecs=5e-4 if name != 'smplx' else 3e-3, shape_betas=6e-5, trans=3e-6)
     for c in ref:
         for k in ref[c]:
             assert np.isfinite(new[c][k]).all(), (c, k)
             assert np.array_equal(new[c][k], again[c][k]), (c, k)
             d = float(np.abs(new[c][k] - ref[c][k]).max())
-            assert (d == 0) if same_kernel else (d < tol.get(k, 5e-4)), (c, k, d)
-        if not same_kernel and c != 'fit_kid':
+            assert d < tol.get(k, tol['pose_rotvecs']), (c, k, d)
+        if c != 'fit_kid':
             va = m(t(new[c]['pose_rotvecs'], dev), t(new[c]['shape_betas'], dev), t(new[c]['trans'], dev))['vertices']
             vb = m(t(ref[c]['pose_rotvecs'], dev), t(ref[c]['shape_betas'], dev), t(ref[c]['trans'], dev))['vertices']
             dv = float((va - vb).norm(dim=-1).max().item())
-            assert dv < 4e-5, (c, 'vertices', dv)
+            assert dv < (8e-5 if name == 'smplx' else 4e-5), (c, 'vertices', dv)
 
 
 @pytest.mark.parametrize('name,B', [('smpl', 4096), ('smpl', 1001), ('smpl', 37), ('smpl1024', 16384), ('smplx', 2304)])
