@@ -275,6 +275,47 @@ def make_targets(m, B, seed, dev, noise=0.0, pose_scale=0.1):
     return tv, tj
 
 
+@pytest.mark.parametrize('name,B', [('smpl', 1100), ('smplx', 1100)])
+def test_coarse_path_vs_oracle(name, B, model_root, golden, dev):
+    """The kernels a LARGE batch runs (above SMPLFIT_FINE_B = 768: the coarse cell tables and, since round 6, the
+    lane = instance stage kernels k_rotations_bm / k_prologue_bm / k_solve_bm / k_refine_bm) straight against the CPU
+    oracle on sampled rows of a 1100-instance batch (every instance is independent, so the oracle fits the sampled rows
+    alone): the gates of test_fit_vs_oracle — mesh 1e-4 m against the fp64 arbiter, shape 3e-4, translation 1e-5, pose no
+    farther from the arbiter than twice the fp32 restatement of the reference is.  Default fit, joints omitted, kid."""
+    from smplfitter_amd.pt import BodyFitter
+
+    g = golden(name)
+    kind, md = util.load_md(model_root, name, g)
+    om64, of64 = util.make_oracle(md, kind, np.float64)
+    _, of32 = util.make_oracle(md, kind, np.float32)
+    m, f = get_model(model_root, name, g, dev)
+    tv, tj = make_targets(m, B, 43, dev, noise=0.005)
+    idx = np.array([0, 1, 63, 64, 555, B - 65, B - 2, B - 1])
+    tvn, tjn = tv[idx].cpu().numpy(), tj[idx].cpu().numpy()
+    for case, kw, joints in (('default', dict(num_iter=3, beta_regularizer=1.0), True),
+                             ('nojoints', dict(num_iter=2, beta_regularizer=0.0), False)):
+        r = f.fit(tv, tj if joints else None, requested_keys=['pose_rotvecs'], **kw)
+        o = {k: r[k][idx].cpu().numpy() for k in ('pose_rotvecs', 'shape_betas', 'trans')}
+        assert all(np.isfinite(v).all() for v in o.values()), case
+        r64 = of64.fit(tvn, tjn if joints else None, **kw)
+        r32 = of32.fit(tvn, tjn if joints else None, **kw)
+        assert util.vertex_l2(om64, o, r64) < 1e-4, case
+        assert np.abs(o['shape_betas'] - r64['shape_betas']).max() < 3e-4, case
+        assert np.abs(o['trans'] - r64['trans']).max() < 1e-5, case
+        ours = np.abs(o['pose_rotvecs'] - r64['pose_rotvecs']).max()
+        ref32 = np.abs(r32['pose_rotvecs'] - r64['pose_rotvecs']).max()
+        assert ours < max(2 * ref32, util.pose_tol(name) if name == 'smplx' else 5e-4), (case, ours, ref32)
+    # the kid unknown (S = 11)
+    ofk = util.O.OracleFitter(om64, enable_kid=True)
+    fk = BodyFitter(m, enable_kid=True)
+    r = fk.fit(tv, tj, num_iter=2, beta_regularizer=1.0, requested_keys=['pose_rotvecs'])
+    rk = ofk.fit(tvn, tjn, num_iter=2, beta_regularizer=1.0)
+    va = om64.forward(r['pose_rotvecs'][idx].cpu().numpy(), r['shape_betas'][idx].cpu().numpy(), r['trans'][idx].cpu().numpy(),
+                      kid_factor=r['kid_factor'][idx].cpu().numpy())['vertices']
+    vb = om64.forward(rk['pose_rotvecs'], rk['shape_betas'], rk['trans'], kid_factor=rk['kid_factor'])['vertices']
+    assert np.linalg.norm(va - vb, axis=-1).max() < 1e-4
+
+
 @pytest.mark.parametrize('name,B', [('smpl', 64), ('smplx', 32)])
 def test_fit_vs_oracle(name, B, model_root, golden, dev, vertex_path):
     """Same seeded inputs through the HIP path and the CPU oracle (fp32 and fp64)."""
